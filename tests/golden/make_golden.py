@@ -1,0 +1,304 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/*.npz from the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference); the fixtures it writes are
+committed, the reference never travels.  Oracle identity recorded in every file:
+"reference @ numpy <ver> / scipy <ver>" (the reference pins neither, requirements.txt:1-7).
+
+How values are captured without touching the reference's files:
+  * cvxpy / line_profiler are absent here and are imported (never used) by
+    sim_src/alg/sdp_solver.py:3 and sim_src/util.py:88 -> two empty stand-in modules.
+  * per-phase locals of mmw._run (sim_src/alg/mmw.py:44-222) are read from the caller's
+    frame inside a wrapper around STATS_OBJECT._add_np_log, which _run calls at the end of
+    every phase (mmw.py:70,142,170,197,200,221).
+  * (L_half, randv) -> X_half pairs come from a recording wrapper installed at the
+    reference's own seam mmw.expm_half_randsk (mmw.py:180,224-229).
+  * rounding draws (sdp_solver.py:48,105) are recorded by wrapping np.random.randn/randint.
+
+Usage:  python tests/golden/make_golden.py   (from the repo root)
+"""
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import scipy
+import scipy.sparse
+import scipy.sparse.linalg
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.modules.setdefault("cvxpy", types.ModuleType("cvxpy"))
+_lp = types.ModuleType("line_profiler")
+_lp.LineProfiler = object
+sys.modules.setdefault("line_profiler", _lp)
+
+from sim_src.alg.mmw import mmw  # noqa: E402  (the reference)
+from sim_src.alg.binary_search_relaxation import binary_search_relaxation  # noqa: E402
+from sim_src.env.env import env  # noqa: E402
+
+META = "reference zhouyou-gu/sig-sdp-mmw @ numpy %s / scipy %s" % (np.__version__, scipy.__version__)
+
+
+def csr_parts(m, prefix):
+    m = scipy.sparse.csr_matrix(m)
+    m.sort_indices()
+    return {prefix + "_indptr": m.indptr.astype(np.int32), prefix + "_indices": m.indices.astype(np.int32),
+            prefix + "_data": m.data.astype(np.float64), prefix + "_shape": np.array(m.shape, dtype=np.int64)}
+
+
+def state_parts(state):
+    S, Q, h = state
+    d = {}
+    d.update(csr_parts(S, "S"))
+    d.update(csr_parts(Q, "Q"))
+    d["h_max"] = np.asarray(h, dtype=np.float64)
+    return d
+
+
+def record_run(state, Z, nit, eta, seed, log_gap):
+    """One mmw.run_with_state with every per-iteration quantity recorded."""
+    out = {"meta": np.array(META), "Z": np.array(Z), "nit": np.array(nit), "eta": np.array(eta),
+           "seed": np.array(seed), "log_gap": np.array(int(log_gap))}
+    out.update(state_parts(state))
+    alg = mmw(nit=nit, eta=eta)
+    alg.LOG_GAP = log_gap
+    rec = {"expm_L": [], "expm_R": [], "expm_X": [], "e_this": [], "e_accu": [], "Y": [], "L_accu": [],
+           "X_mdiag": [], "X_offdi": []}
+    pattern = {}
+
+    orig_seam = mmw.expm_half_randsk
+
+    def seam(L, D):
+        # same body as mmw.py:224-229, with the draw recorded
+        randv = np.random.randn(L.shape[0], D) / math.sqrt(float(D))
+        randv = randv / np.linalg.norm(randv, axis=1)[:, None]
+        ret = scipy.sparse.linalg.expm_multiply(L.copy(), randv)
+        Lc = scipy.sparse.csr_matrix(L)
+        Lc.sort_indices()
+        rec["expm_L"].append(Lc)
+        rec["expm_R"].append(randv.copy())
+        rec["expm_X"].append(ret.copy())
+        return ret
+
+    orig_log = alg._add_np_log
+
+    def log(key, step, row, g_step=0):
+        loc = sys._getframe(1).f_locals
+        if key == "mmw_state_process":
+            ST = loc["S_gain_T_no_asso_no_diag"]
+            pattern["ST_format"] = ST.format
+            pattern["ST"] = scipy.sparse.csr_matrix(ST)
+            pattern["S_sum"] = loc["S_sum"].copy()
+            pattern["norm_H"] = loc["norm_H"].copy()
+            for n in ("nz_idx_gain_x_ut", "nz_idx_gain_y_ut", "nz_idx_asso_x_ut", "nz_idx_asso_y_ut"):
+                pattern[n] = np.asarray(loc[n]).astype(np.int32)
+            pattern["C"] = loc["C"]
+            pattern["E_asso"] = loc["E_asso"]
+        elif key == "mmw_dual":
+            rec["e_this"].append(loc["e_this"].copy())
+            rec["e_accu"].append(loc["e_accu"].copy())
+            rec["Y"].append(loc["Y"].copy())
+        elif key == "mmw_loss":
+            rec["L_accu"].append(scipy.sparse.csr_matrix(loc["L_accu"]))
+        elif key == "mmw_expm":
+            rec["X_mdiag"].append(np.asarray(loc["X_mdiag"].diagonal()).copy())
+            rec["X_offdi"].append(scipy.sparse.csr_matrix(loc["X_offdi"]))
+        elif key == "mmw_xavg":
+            pattern["X_avgd"] = scipy.sparse.csr_matrix(loc["X_avgd"])
+        return orig_log(key, step, row, g_step)
+
+    alg._add_np_log = log
+    mmw.expm_half_randsk = staticmethod(seam)
+    try:
+        np.random.seed(seed)
+        ok, X_half = alg.run_with_state(0, Z, state)
+        rng_after = np.random.get_state()[2]
+    finally:
+        mmw.expm_half_randsk = orig_seam
+
+    out["ST_format"] = np.array(pattern["ST_format"])
+    out.update(csr_parts(pattern["ST"], "ST"))
+    out["S_sum"] = pattern["S_sum"]
+    out["norm_H"] = pattern["norm_H"]
+    for n in ("nz_idx_gain_x_ut", "nz_idx_gain_y_ut", "nz_idx_asso_x_ut", "nz_idx_asso_y_ut"):
+        out[n] = pattern[n]
+    out["C"] = np.array(pattern["C"])
+    out["E_asso"] = np.array(pattern["E_asso"])
+    # per-iteration stacks; sparse things are stored densely only when tiny, else as CSR per iteration
+    out["randv"] = np.stack(rec["expm_R"])
+    out["X_half_it"] = np.stack(rec["expm_X"])
+    out["e_this"] = np.stack(rec["e_this"])
+    out["e_accu"] = np.stack(rec["e_accu"])
+    out["Y"] = np.stack(rec["Y"])
+    out["X_mdiag"] = np.stack(rec["X_mdiag"])
+    for i in range(nit):
+        out.update(csr_parts(rec["expm_L"][i], "Lhalf%d" % i))
+        out.update(csr_parts(rec["L_accu"][i], "Laccu%d" % i))
+        out.update(csr_parts(rec["X_offdi"][i], "Xoffdi%d" % i))
+    out.update(csr_parts(pattern["X_avgd"], "Xavgd"))
+    out["X_half_ret"] = X_half
+    out["rng_pos_after"] = np.array(rng_after)
+    for key in ("gap", "mmw_dual", "mmw_loss", "mmw_expm", "mmw_per_it", "mmw_xavg", "mmw_all_it", "mmw_state_process"):
+        if key in alg.LOGGED_NP_DATA:
+            out["log_" + key + "_shape"] = np.array(alg.LOGGED_NP_DATA[key].shape)
+    if log_gap:
+        out["gap"] = alg.LOGGED_NP_DATA["gap"][:, 3:].copy()
+    return out, alg, X_half
+
+
+def record_rounding(alg, Z, gX, state, seed, nattempt=10):
+    """sdp_solver.rounding (sdp_solver.py:18-25) with the draws of every attempt recorded."""
+    draws = {"randn": [], "randint": []}
+    o_randn, o_randint = np.random.randn, np.random.randint
+
+    def randn(*a):
+        r = o_randn(*a)
+        draws["randn"].append(r.copy())
+        return r
+
+    def randint(*a, **k):
+        r = o_randint(*a, **k)
+        draws["randint"].append(np.asarray(r).copy())
+        return r
+
+    np.random.seed(seed)
+    np.random.randn, np.random.randint = randn, randint
+    try:
+        z_vec, Zr, rem = alg.rounding(Z, gX, state, nattempt=nattempt)
+    finally:
+        np.random.randn, np.random.randint = o_randn, o_randint
+    out = {"round_seed": np.array(seed), "round_gX": gX, "round_Z": np.array(Z), "round_z_vec": z_vec,
+           "round_rem": np.array(int(rem)), "round_nattempt_used": np.array(len(draws["randn"])),
+           "round_randv": np.stack(draws["randn"])}
+    if draws["randint"]:
+        out["round_randint_last"] = draws["randint"][-1]
+        out["round_randint_count"] = np.array(len(draws["randint"]))
+    return out
+
+
+def record_one_attempts(alg, Z, gX, state, seed, n):
+    """n independent single attempts (sdp_solver.py:27-107): each (randv) -> (z_vec, remainder, mask)."""
+    outs = {"att_randv": [], "att_z": [], "att_rem": [], "att_randint": []}
+    o_randn, o_randint = np.random.randn, np.random.randint
+    np.random.seed(seed)
+    for _ in range(n):
+        cap = {}
+
+        def randn(*a):
+            r = o_randn(*a)
+            cap["randv"] = r.copy()
+            return r
+
+        def randint(*a, **k):
+            r = o_randint(*a, **k)
+            cap["randint"] = np.asarray(r).copy()
+            return r
+
+        np.random.randn, np.random.randint = randn, randint
+        try:
+            z_vec, Zr, rem = alg.rounding_one_attempt(Z, gX, state)
+        finally:
+            np.random.randn, np.random.randint = o_randn, o_randint
+        outs["att_randv"].append(cap["randv"])
+        outs["att_z"].append(z_vec.copy())
+        outs["att_rem"].append(int(rem))
+        ri = cap.get("randint", np.zeros(0, dtype=np.int64))
+        pad = np.full(gX.shape[0], -1, dtype=np.int64)
+        pad[:ri.size] = ri
+        outs["att_randint"].append(pad)
+    return {k: np.stack(v) if k != "att_rem" else np.array(v) for k, v in outs.items()}
+
+
+def synthetic_state(K, p, seed):
+    from sig_sdp_mmw_amd.graphs import er_contention_graph
+    return er_contention_graph(K, p, seed)
+
+
+def main():
+    cases = [
+        # name, state factory, Z, nit, eta, seed, log_gap, Z_round (slot count used for the tight rounding fixture)
+        ("env75", lambda: env(cell_size=5, sta_density_per_1m2=75e-4, seed=0).generate_S_Q_hmax(), 27, 8, 0.04, 11, True),
+        ("env300", lambda: env(cell_size=10, sta_density_per_1m2=75e-4, seed=0).generate_S_Q_hmax(), 12, 4, 0.1, 12, False),
+        ("env192", lambda: env(cell_size=8, sta_density_per_1m2=75e-4, seed=3).generate_S_Q_hmax(), 20, 5, 0.05, 13, True),
+        ("er120", lambda: synthetic_state(120, 0.2, 5), 9, 6, 0.04, 14, False),
+        ("dense60", lambda: synthetic_state(60, 1.0, 6), 16, 5, 0.04, 15, True),
+    ]
+    for name, mk, Z, nit, eta, seed, log_gap in cases:
+        state = mk()
+        out, alg, X_half = record_run(state, Z, nit, eta, seed, log_gap)
+        out.update(record_rounding(alg, Z, X_half, state, seed + 100))
+        out.update(record_one_attempts(alg, Z, X_half, state, seed + 200, 3))
+        # a deliberately too-small slot count: forces infeasible users -> remainder > 0, randint leftovers
+        Zs = max(3, Z // 3)
+        gXs = X_half[:, :max(1, min(X_half.shape[1], (Zs - 1) * 2))]
+        small = record_one_attempts(alg, Zs, gXs, state, seed + 300, 2)
+        out.update({"small_" + k: v for k, v in small.items()})
+        out["small_Z"] = np.array(Zs)
+        out["small_gX"] = gXs
+        path = os.path.join(HERE, "run_%s.npz" % name)
+        np.savez_compressed(path, **out)
+        print(name, "K=%d" % state[0].shape[0], "rem=%d" % int(out["round_rem"]), "small rem", small["att_rem"],
+              "%.0f KB" % (os.path.getsize(path) / 1024))
+
+    # the expm seam alone, at larger norms than the MMW loop reaches (exercises the adaptive Krylov order)
+    state = env(cell_size=6, sta_density_per_1m2=75e-4, seed=1).generate_S_Q_hmax()
+    out, alg, _ = record_run(state, 20, 3, 0.04, 21, False)
+    K = state[0].shape[0]
+    Lc = scipy.sparse.csr_matrix((out["Lhalf2_data"], out["Lhalf2_indices"], out["Lhalf2_indptr"]), shape=(K, K))
+    seam = {"meta": np.array(META)}
+    seam.update(csr_parts(Lc, "L"))
+    scales = np.array([1.0, 30.0, 300.0, 3000.0])
+    seam["scales"] = scales
+    for i, s in enumerate(scales):
+        captured = {}
+        o_randn = np.random.randn
+
+        def randn(*a):
+            r = o_randn(*a)
+            captured["g"] = r.copy()
+            return r
+
+        np.random.seed(40 + i)
+        np.random.randn = randn
+        try:
+            Ls = Lc.copy()
+            Ls.data = Ls.data * s
+            X = mmw.expm_half_randsk(Ls, 8)
+        finally:
+            np.random.randn = o_randn
+        g = captured["g"] / math.sqrt(8.0)
+        seam["randv%d" % i] = g / np.linalg.norm(g, axis=1)[:, None]
+        seam["X%d" % i] = X
+        seam["onenorm%d" % i] = np.array(abs(Ls - (Ls.diagonal().sum() / K) * scipy.sparse.identity(K)).sum(axis=0).max())
+    path = os.path.join(HERE, "expm_seam.npz")
+    np.savez_compressed(path, **seam)
+    print("expm_seam", [float(seam["onenorm%d" % i]) for i in range(len(scales))], "%.0f KB" % (os.path.getsize(path) / 1024))
+
+    # end-to-end binary search (binary_search_relaxation.py:31-72) under the reference solver
+    bs_out = {"meta": np.array(META)}
+    for name, mk, seed in [("env75", lambda: env(cell_size=5, sta_density_per_1m2=75e-4, seed=0).generate_S_Q_hmax(), 7),
+                           ("env108", lambda: env(cell_size=6, sta_density_per_1m2=75e-4, seed=2).generate_S_Q_hmax(), 8)]:
+        state = mk()
+        bs = binary_search_relaxation()
+        alg = mmw(nit=30, eta=0.04)
+        bs.feasibility_check_alg = alg
+        np.random.seed(seed)
+        z_vec, Zf, rem = bs.run(state)
+        bs_out.update({name + "_" + k: v for k, v in state_parts(state).items()})
+        bs_out[name + "_seed"] = np.array(seed)
+        bs_out[name + "_z_vec"] = z_vec
+        bs_out[name + "_Z"] = np.array(Zf)
+        bs_out[name + "_rem"] = np.array(int(rem))
+        bs_out[name + "_per_it"] = bs.LOGGED_NP_DATA["bs_search_per_it"][:, 3:8].copy()
+        bs_out[name + "_bounds"] = bs.LOGGED_NP_DATA["bs_set_bounds"][:, 3:5].copy()
+    path = os.path.join(HERE, "bs_run.npz")
+    np.savez_compressed(path, **bs_out)
+    print("bs_run %.0f KB" % (os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    main()
