@@ -1,0 +1,155 @@
+/*
+ * mmw_hip.h -- C ABI of the MI355X (gfx950) MMW SDP hot path.
+ *
+ * The reference (zhouyou-gu/sig-sdp-mmw) is pure Python and has no FFI; its boundary for this path
+ * is the duck-typed solver protocol
+ *
+ *     f, gX          = alg.run_with_state(it, Z, state)   sim_src/alg/binary_search_relaxation.py:50
+ *     z_vec, Z, rem  = alg.rounding(Z, gX, state)         sim_src/alg/binary_search_relaxation.py:53
+ *
+ * implemented by class mmw (sim_src/alg/mmw.py:12-229) and sdp_solver.rounding
+ * (sim_src/alg/sdp_solver.py:18-107).  The entry points below are what a ctypes binding of that class
+ * calls (see INTEGRATION.md for the stub); each one cites the reference lines it replaces.
+ *
+ * Conventions: C linkage, plain pointers + sizes, no exceptions cross the ABI.  Every function returns
+ * 0 on success or a negative status; mmw_last_error() gives the message of the calling thread's last
+ * failure.  Host buffers are caller-owned (NumPy arrays); device memory is library-owned.  One handle =
+ * one device + one HIP stream.  A handle is not thread-safe; different handles may be used
+ * concurrently (the library keeps no mutable global state besides the thread-local error string).
+ * All host-side floating point crosses the ABI as float64 whatever the device compute type is.
+ */
+#ifndef MMW_HIP_H
+#define MMW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mmw_solver mmw_solver;
+
+#define MMW_OK 0
+#define MMW_ERR_ARG (-1)     /* bad argument / malformed state */
+#define MMW_ERR_HIP (-2)     /* a HIP runtime call failed (no device, OOM, launch failure) */
+#define MMW_ERR_STATE (-3)   /* call out of order (e.g. iterate past nit) */
+
+enum mmw_dtype { MMW_F32 = 0, MMW_F64 = 1 };
+enum mmw_expm_method {
+    MMW_EXPM_LANCZOS = 0, /* per-column Lanczos, exp of the small tridiagonals on device */
+    MMW_EXPM_TAYLOR = 1   /* shifted truncated Taylor (the scheme scipy's expm_multiply runs) */
+};
+
+/* selectors for mmw_read_f64 / mmw_read_i32 */
+enum mmw_field {
+    MMW_F_Y = 0,          /* [C]      dual weights Y (mmw.py:139)                       */
+    MMW_F_E_ACCU = 1,     /* [C]      accumulated violations e_accu (mmw.py:137)        */
+    MMW_F_E_THIS = 2,     /* [C]      last e_this (mmw.py:136)                          */
+    MMW_F_LVAL = 3,       /* [nnzL]   L_accu on the fixed pattern (mmw.py:167)          */
+    MMW_F_XVAL = 4,       /* [nnzL]   X on the pattern, diagonal included (mmw.py:183-194) */
+    MMW_F_XAVG = 5,       /* [nnzL]   running sum of X (mmw.py:77), not yet divided     */
+    MMW_F_YAVG = 6,       /* [C]      running sum of Y (mmw.py:78)                      */
+    MMW_F_XHALF = 7,      /* [K*D]    last exp(L/2) R, row-major (mmw.py:180)           */
+    MMW_F_SKETCH = 8,     /* [K*D]    last row-normalised sketch R (mmw.py:226-227)     */
+    MMW_F_S_SUM = 9,      /* [K]      S_sum  (mmw.py:34)                                */
+    MMW_F_NORM_H = 10,    /* [K]      norm_H (mmw.py:39)                                */
+    MMW_F_ST_DATA = 11,   /* [nnzST]  values of S_T' in CSR order (mmw.py:28-33)        */
+    MMW_F_PHASE_US = 12,  /* [4*iters] per-iteration device us: dual, loss, expm, total (mmw.py:141,169,196,199) */
+    MMW_F_EXPM_INFO = 13, /* [4]      last plan: one-norm bound, Krylov order m, substeps, shift mu */
+    MMW_F_FACTOR = 14     /* [K*rank] last factor of the averaged X (mmw.py:213-216)    */
+};
+enum mmw_ifield {
+    MMW_I_L_INDPTR = 0,   /* [K+1]   */
+    MMW_I_L_INDICES = 1,  /* [nnzL]  */
+    MMW_I_ST_INDPTR = 2,  /* [K+1]   */
+    MMW_I_ST_INDICES = 3, /* [nnzST] */
+    MMW_I_GAIN_X = 4,     /* [E_gain] nz_idx_gain_x_ut (mmw.py:56) */
+    MMW_I_GAIN_Y = 5,
+    MMW_I_ASSO_X = 6,     /* [E_asso] nz_idx_asso_x_ut (mmw.py:57) */
+    MMW_I_ASSO_Y = 7,
+    MMW_I_DIAG_POS = 8,   /* [K] position of (k,k) in the L pattern */
+    MMW_I_ASSO_POS = 9    /* [E_asso] position of (x,y), x<y, in the L pattern */
+};
+
+const char* mmw_last_error(void);
+int mmw_version(void);
+/* number of visible HIP devices; does not create a context */
+int mmw_device_count(int* n);
+
+/*
+ * mmw_create: mmw._process_state + the prologue of mmw._run (mmw.py:26-41, 46-74).
+ * Takes `state` exactly as the reference's caller hands it over: S_gain and Q_asso as canonical CSR
+ * (sorted indices, no duplicates; int32 index arrays as scipy stores them), h_max[K].  Builds S_T',
+ * S_sum, norm_H, the edge lists and the fixed CSR pattern of L/X in native host code, copies them to
+ * `device` once and sets the iterate to the reference's initial point (Y = 1/C, X = I, L = 0).
+ * The inputs are not modified (the reference copies them too, mmw.py:28).
+ * device == -1 builds the host-side pattern only (no HIP call): such a handle answers mmw_sizes,
+ * mmw_read_i32 and the host fields S_SUM / NORM_H / ST_DATA, everything else returns MMW_ERR_STATE.
+ */
+int mmw_create(mmw_solver** out, int device, int dtype, int32_t K, int32_t Z, int32_t rank_radio, double eta,
+               int32_t nit, const int32_t* S_indptr, const int32_t* S_indices, const double* S_data,
+               const int32_t* Q_indptr, const int32_t* Q_indices, const double* Q_data, const double* h_max);
+int mmw_destroy(mmw_solver* s);
+
+/* out[0..9] = K, Z, D, Dpad, nnzL, nnzST, E_gain, E_asso, C, iterations done */
+int mmw_sizes(mmw_solver* s, int64_t out[10]);
+
+/* Krylov scheme for exp(L/2)R, max order per substep (<= 16) and target relative accuracy. */
+int mmw_set_expm(mmw_solver* s, int method, int max_order, double tol);
+/* 1: record HIP events around every phase (fills MMW_F_PHASE_US); 0: none, iterations run back to back. */
+int mmw_set_timing(mmw_solver* s, int enabled);
+
+/* back to the initial point of mmw.py:62-73 for a fresh run of `nit` iterations on the same (state, Z) */
+int mmw_reset(mmw_solver* s, int32_t nit);
+
+/*
+ * mmw_iterate: `n` passes of the loop body mmw.py:75-200 (averaging, DUAL, LOSS, EXPM), device resident.
+ * randv: NULL -> the sketch of every iteration is generated on the device (Philox4x32-10 normals,
+ * counter = (seed, iteration, row, column), rows normalised); otherwise n*K*D float64, iteration-major,
+ * each block the row-normalised (K,D) sketch the reference would draw at mmw.py:226-227 (parity mode).
+ * Returns after the work is enqueued; any read or mmw_sync waits for it.
+ */
+int mmw_iterate(mmw_solver* s, int32_t n, const double* randv, uint64_t seed);
+int mmw_sync(mmw_solver* s);
+
+int mmw_read_f64(mmw_solver* s, int which, double* out, int64_t n);
+int mmw_read_i32(mmw_solver* s, int which, int32_t* out, int64_t n);
+
+/*
+ * mmw_gap: the LOG_GAP branch mmw.py:79-117 at the current averages (call before iteration i with
+ * i+1 terms accumulated): out = { max_c e_c(Xbar), K*lambda_min(L(Ybar)), difference }.
+ */
+int mmw_gap(mmw_solver* s, double out[3]);
+
+/*
+ * mmw_factor: the epilogue mmw.py:202-216.  Xbar = (sum of X)/nit on the pattern, top-`rank`
+ * (by |eigenvalue|) invariant subspace by block Krylov iteration on the device,
+ * X_half[K,rank] = V sqrt(|lambda|), columns in ascending |lambda| like svds.  out: K*rank float64.
+ */
+int mmw_factor(mmw_solver* s, int32_t rank, double* out, uint64_t seed);
+
+/*
+ * mmw_expm_apply: the stand-alone seam mmw.expm_half_randsk (mmw.py:224-229) minus the draw:
+ * out[K,D] = exp(A) B for a symmetric CSR matrix A (pattern arbitrary) and a dense block B.
+ * info (may be NULL): one-norm bound, order m, substeps, shift.  `reps` > 1 repeats the device work
+ * (benchmarking); kernel_us (may be NULL) receives the mean device time of one application.
+ */
+int mmw_expm_apply(int device, int dtype, int method, int max_order, double tol, int32_t K, int32_t D,
+                   const int32_t* indptr, const int32_t* indices, const double* data, const double* B,
+                   double* out, double info[4], int32_t reps, double* kernel_us);
+
+/*
+ * mmw_round: one sdp_solver.rounding_one_attempt (sdp_solver.py:27-107) per projection batch entry.
+ * gX[K,Dp] and randv[nbatch,Z,Dp] (row-normalised, sdp_solver.py:48-49) in float64.  For every batch
+ * entry: inprod = randv gX^T on the fp64 matrix cores, per-user slot preference order, the greedy
+ * feasibility assignment in descending ||gX_k|| order.  z_out[nbatch,K] gets the slot or -1 for a user
+ * left unassigned (the caller draws those, sdp_solver.py:104-105); rem_out[nbatch] the count.
+ */
+int mmw_round(mmw_solver* s, int32_t Zr, int32_t Dp, const double* gX, int32_t nbatch, const double* randv,
+              int32_t* z_out, int32_t* rem_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMW_HIP_H */

@@ -1,0 +1,240 @@
+"""ctypes binding of include/mmw_hip.h (the only way the Python host reaches the GPU).
+
+There is no CPU fallback: if `libmmw_hip.so` is missing or cannot be loaded this module raises, and
+every entry point raises `MMWError` with the library's message on a non-zero status.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmw_hip.so")
+
+F32, F64 = 0, 1
+EXPM_LANCZOS, EXPM_TAYLOR = 0, 1
+
+# enum mmw_field / mmw_ifield
+F_Y, F_E_ACCU, F_E_THIS, F_LVAL, F_XVAL, F_XAVG, F_YAVG, F_XHALF, F_SKETCH = range(9)
+F_S_SUM, F_NORM_H, F_ST_DATA, F_PHASE_US, F_EXPM_INFO, F_FACTOR = range(9, 15)
+I_L_INDPTR, I_L_INDICES, I_ST_INDPTR, I_ST_INDICES, I_GAIN_X, I_GAIN_Y, I_ASSO_X, I_ASSO_Y, I_DIAG_POS, I_ASSO_POS = range(10)
+
+EXPORTS = ["mmw_last_error", "mmw_version", "mmw_device_count", "mmw_create", "mmw_destroy", "mmw_sizes", "mmw_set_expm",
+           "mmw_set_timing", "mmw_reset", "mmw_iterate", "mmw_sync", "mmw_read_f64", "mmw_read_i32", "mmw_gap",
+           "mmw_factor", "mmw_expm_apply", "mmw_round"]
+
+
+class MMWError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library once; raise loudly if it is absent (build it with `python __graft_entry__.py`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MMWError("HIP library %s not found: build it first (python -c 'import __graft_entry__ as g; g.build()'). "
+                       "There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    p_i32 = C.POINTER(C.c_int32)
+    p_f64 = C.POINTER(C.c_double)
+    L.mmw_last_error.restype = C.c_char_p
+    L.mmw_last_error.argtypes = []
+    L.mmw_version.restype = C.c_int
+    L.mmw_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.mmw_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32,
+                             p_i32, p_i32, p_f64, p_i32, p_i32, p_f64, p_f64]
+    L.mmw_destroy.argtypes = [C.c_void_p]
+    L.mmw_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    L.mmw_set_expm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double]
+    L.mmw_set_timing.argtypes = [C.c_void_p, C.c_int]
+    L.mmw_reset.argtypes = [C.c_void_p, C.c_int32]
+    L.mmw_iterate.argtypes = [C.c_void_p, C.c_int32, p_f64, C.c_uint64]
+    L.mmw_sync.argtypes = [C.c_void_p]
+    L.mmw_read_f64.argtypes = [C.c_void_p, C.c_int, p_f64, C.c_int64]
+    L.mmw_read_i32.argtypes = [C.c_void_p, C.c_int, p_i32, C.c_int64]
+    L.mmw_gap.argtypes = [C.c_void_p, p_f64]
+    L.mmw_factor.argtypes = [C.c_void_p, C.c_int32, p_f64, C.c_uint64]
+    L.mmw_expm_apply.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int32, C.c_int32, p_i32, p_i32, p_f64,
+                                 p_f64, p_f64, p_f64, C.c_int32, p_f64]
+    L.mmw_round.argtypes = [C.c_void_p, C.c_int32, C.c_int32, p_f64, C.c_int32, p_f64, p_i32, p_i32]
+    for name in EXPORTS:
+        if name not in ("mmw_last_error",):
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise MMWError("mmw_hip status %d: %s" % (rc, lib().mmw_last_error().decode("utf-8", "replace")))
+
+
+def _pi(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _pd(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().mmw_device_count(C.byref(n)))
+    return n.value
+
+
+def canonical_csr(m):
+    """scipy CSR with sorted, de-duplicated indices as int32/float64 arrays (copies only when needed)."""
+    import scipy.sparse
+    m = scipy.sparse.csr_matrix(m)
+    if not m.has_canonical_format:
+        m = m.copy()
+        m.sum_duplicates()
+    return _i32(m.indptr), _i32(m.indices), _f64(m.data)
+
+
+class Solver:
+    """Owning wrapper of one `mmw_solver*` handle."""
+
+    def __init__(self, Z, state, nit, eta, rank_radio=2, dtype=F64, device=0):
+        S, Q, h = state
+        self.K = int(S.shape[0])
+        if S.shape != (self.K, self.K) or Q.shape != (self.K, self.K) or len(h) != self.K:
+            raise MMWError("state must be (S_gain KxK, Q_asso KxK, h_max[K])")
+        sp, si, sx = canonical_csr(S)
+        qp, qi, qx = canonical_csr(Q)
+        hm = _f64(h)
+        self._h = C.c_void_p()
+        check(lib().mmw_create(C.byref(self._h), int(device), int(dtype), self.K, int(Z), int(rank_radio), float(eta), int(nit),
+                               _pi(sp), _pi(si), _pd(sx), _pi(qp), _pi(qi), _pd(qx), _pd(hm)))
+        sz = (C.c_int64 * 10)()
+        check(lib().mmw_sizes(self._h, sz))
+        (self.K, self.Z, self.D, self.Dpad, self.nnzL, self.nnzST, self.E_gain, self.E_asso, self.C, _) = [int(x) for x in sz]
+        self.dtype = dtype
+        self._timing = False
+        self._timed = 0
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().mmw_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def iterations_done(self):
+        sz = (C.c_int64 * 10)()
+        check(lib().mmw_sizes(self._h, sz))
+        return int(sz[9])
+
+    def set_expm(self, method=EXPM_LANCZOS, max_order=12, tol=1e-9):
+        check(lib().mmw_set_expm(self._h, int(method), int(max_order), float(tol)))
+
+    def set_timing(self, on):
+        check(lib().mmw_set_timing(self._h, 1 if on else 0))
+        self._timing = bool(on)
+
+    def reset(self, nit):
+        check(lib().mmw_reset(self._h, int(nit)))
+        self._timed = 0
+
+    def iterate(self, n, randv=None, seed=0):
+        if self._timing:
+            self._timed += int(n)
+        if randv is None:
+            check(lib().mmw_iterate(self._h, int(n), None, C.c_uint64(int(seed))))
+        else:
+            r = _f64(randv)
+            if r.size != n * self.K * self.D:
+                raise MMWError("randv must hold n*K*D = %d values, got %d" % (n * self.K * self.D, r.size))
+            check(lib().mmw_iterate(self._h, int(n), _pd(r), C.c_uint64(0)))
+
+    def sync(self):
+        check(lib().mmw_sync(self._h))
+
+    _LEN = {F_Y: "C", F_E_ACCU: "C", F_E_THIS: "C", F_LVAL: "nnzL", F_XVAL: "nnzL", F_XAVG: "nnzL", F_YAVG: "C",
+            F_S_SUM: "K", F_NORM_H: "K", F_ST_DATA: "nnzST"}
+
+    def read(self, which, n=None):
+        if n is None:
+            if which in (F_XHALF, F_SKETCH):
+                n = self.K * self.D
+            elif which == F_EXPM_INFO:
+                n = 4
+            elif which == F_PHASE_US:
+                n = 4 * self._timed_iters()
+            else:
+                n = getattr(self, self._LEN[which])
+        out = np.empty(int(n), dtype=np.float64)
+        check(lib().mmw_read_f64(self._h, int(which), _pd(out), int(n)))
+        if which in (F_XHALF, F_SKETCH):
+            out = out.reshape(self.K, self.D)
+        return out
+
+    def _timed_iters(self):
+        return self._timed
+
+    _ILEN = {I_L_INDPTR: lambda s: s.K + 1, I_L_INDICES: lambda s: s.nnzL, I_ST_INDPTR: lambda s: s.K + 1,
+             I_ST_INDICES: lambda s: s.nnzST, I_GAIN_X: lambda s: s.E_gain, I_GAIN_Y: lambda s: s.E_gain,
+             I_ASSO_X: lambda s: s.E_asso, I_ASSO_Y: lambda s: s.E_asso, I_DIAG_POS: lambda s: s.K,
+             I_ASSO_POS: lambda s: s.E_asso}
+
+    def read_i32(self, which):
+        n = self._ILEN[which](self)
+        out = np.empty(int(n), dtype=np.int32)
+        check(lib().mmw_read_i32(self._h, int(which), _pi(out), int(n)))
+        return out
+
+    def gap(self):
+        out = np.empty(3, dtype=np.float64)
+        check(lib().mmw_gap(self._h, _pd(out)))
+        return out
+
+    def factor(self, rank, seed=0):
+        out = np.empty((self.K, int(rank)), dtype=np.float64)
+        check(lib().mmw_factor(self._h, int(rank), _pd(out), C.c_uint64(int(seed))))
+        return out
+
+    def round(self, Z, gX, randv):
+        """randv: (nbatch, Z, D') row-normalised; returns (z[nbatch,K] int32 with -1 = unassigned, rem[nbatch])."""
+        gX = _f64(gX)
+        randv = _f64(randv)
+        if randv.ndim == 2:
+            randv = randv[None]
+        nb, Zr, Dp = randv.shape
+        if Zr != Z or gX.shape != (self.K, Dp):
+            raise MMWError("round: gX must be (K, D') and randv (nbatch, Z, D')")
+        z = np.empty((nb, self.K), dtype=np.int32)
+        rem = np.empty(nb, dtype=np.int32)
+        check(lib().mmw_round(self._h, int(Z), int(Dp), _pd(gX), int(nb), _pd(randv), _pi(z), _pi(rem)))
+        return z, rem
+
+
+def expm_apply(A_csr, B, dtype=F64, method=EXPM_LANCZOS, max_order=12, tol=1e-9, device=0, reps=1):
+    """exp(A) B on the device for a symmetric scipy CSR matrix A; returns (out, info dict)."""
+    ip, ci, vv = canonical_csr(A_csr)
+    B = _f64(B)
+    K, D = B.shape
+    out = np.empty((K, D), dtype=np.float64)
+    info = np.zeros(4, dtype=np.float64)
+    us = C.c_double(0.0)
+    check(lib().mmw_expm_apply(int(device), int(dtype), int(method), int(max_order), float(tol), K, D, _pi(ip), _pi(ci), _pd(vv),
+                               _pd(B), _pd(out), _pd(info), int(reps), C.byref(us)))
+    return out, {"one_norm": info[0], "order": int(info[1]), "substeps": int(info[2]), "shift": info[3], "kernel_us": us.value}

@@ -1,0 +1,172 @@
+// Host orchestration of exp(ascale * A) B on one stream: planning (one-norm bound -> order, substeps),
+// per-column Lanczos or shifted Taylor on top of the CSR SpMM.  Used by the MMW loop (A = L_accu, ascale = 1/2)
+// and by the stand-alone seam mmw_expm_apply.
+#pragma once
+#include <cmath>
+
+#include "kernels_expm.h"
+#include "runtime.h"
+
+namespace mmw {
+
+inline int make_layout(int D, int vec, BlockLayout& lay, std::string& err) {
+    int lpr = (D + vec - 1) / vec;
+    if (lpr <= 32) {
+        int p = 1;
+        while (p < lpr) p <<= 1;
+        lpr = p;
+        lay.G = WAVE / lpr;
+        lay.NCH = 1;
+    } else {
+        lay.G = 1;
+        lay.NCH = (lpr + WAVE - 1) / WAVE;
+        if (lay.NCH > 4) {
+            err = "sketch width D too large for this build (max 1024 f32 / 512 f64 columns)";
+            return MMW_ERR_ARG;
+        }
+    }
+    lay.D = D;
+    lay.LPR = lpr;
+    lay.Dpad = lpr * vec;
+    return MMW_OK;
+}
+
+template <typename T> struct ExpmEngine {
+    hipStream_t st = nullptr;
+    int K = 0;
+    BlockLayout lay{};
+    int method = MMW_EXPM_LANCZOS, max_order = 8;
+    double tol = 1e-9;
+    int nblk = 1;
+    const int* indptr = nullptr;
+    const int* col = nullptr;
+    const T* val = nullptr;
+    DevBuf<T> U;        // (max_order + 1) blocks of K*Dpad; block 0 is the start block
+    DevBuf<T> Tm;       // A * U_j
+    DevBuf<double> partial, colsum, scal, rho_part, trace_own;
+    DevBuf<ExpmPlan> plan_d;
+    ExpmPlan* plan_h = nullptr;  // pinned
+    ExpmPlan last{};
+    size_t bs = 0;      // elements per block
+    double spmm_ms_accum = 0.0;
+
+    ~ExpmEngine() {
+        if (plan_h) (void)hipHostFree(plan_h);
+    }
+    int init(hipStream_t s, int K_, int D, const int* ip, const int* ci, const T* v) {
+        st = s;
+        K = K_;
+        indptr = ip;
+        col = ci;
+        val = v;
+        std::string err;
+        if (make_layout(D, V16<T>::N, lay, err) != MMW_OK) return fail(MMW_ERR_ARG, err);
+        bs = (size_t)K * lay.Dpad;
+        nblk = grid_rows(K);
+        MMW_TRY(U.alloc(bs * (size_t)(MAX_ORDER + 1)));
+        MMW_TRY(Tm.alloc(bs));
+        MMW_TRY(partial.alloc((size_t)MAX_PART * lay.Dpad));
+        MMW_TRY(colsum.alloc(lay.Dpad));
+        MMW_TRY(scal.alloc((size_t)4 * (MAX_ORDER + 2) * lay.Dpad));
+        MMW_TRY(rho_part.alloc(MAX_PART));
+        MMW_TRY(trace_own.alloc(MAX_PART));
+        MMW_TRY(plan_d.alloc(1));
+        MMW_HIP(hipHostMalloc((void**)&plan_h, sizeof(ExpmPlan)));
+        MMW_HIP(hipMemsetAsync(U.p, 0, bs * (size_t)(MAX_ORDER + 1) * sizeof(T), st));
+        return MMW_OK;
+    }
+    T* start_block() { return U.p; }
+    T* block(int j) { return U.p + (size_t)j * bs; }  // U_j lives in block j-1
+    LanczosScalars scalars() {
+        LanczosScalars S;
+        const size_t n = (size_t)(MAX_ORDER + 2) * lay.Dpad;
+        S.alpha = scal.p;
+        S.beta = scal.p + n;
+        S.sinv = scal.p + 2 * n;
+        S.coef = scal.p + 3 * n;
+        return S;
+    }
+
+    template <int MODE> int launch_spmm(const T* in, T* out, T* F, double ascale, double shift, double inv_k) {
+        const size_t sh = MODE == SPMM_LANCZOS ? (size_t)WAVES_PER_BLOCK * lay.Dpad * sizeof(double) : 0;
+        switch (lay.NCH) {
+            case 1: hipLaunchKernelGGL((k_spmm<T, 1, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, ascale, shift, inv_k, partial.p); break;
+            case 2: hipLaunchKernelGGL((k_spmm<T, 2, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, ascale, shift, inv_k, partial.p); break;
+            case 3: hipLaunchKernelGGL((k_spmm<T, 3, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, ascale, shift, inv_k, partial.p); break;
+            default: hipLaunchKernelGGL((k_spmm<T, 4, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, ascale, shift, inv_k, partial.p); break;
+        }
+        MMW_HIP(hipGetLastError());
+        return MMW_OK;
+    }
+    int colreduce(int nb) {
+        hipLaunchKernelGGL(k_colreduce, dim3((lay.Dpad + 15) / 16), dim3(BLOCK), 0, st, nb, lay.Dpad, partial.p, colsum.p);
+        MMW_HIP(hipGetLastError());
+        return MMW_OK;
+    }
+
+    // plan from the current values; trace_part: per-block diagonal sums made by the producer (or null)
+    int make_plan(double ascale, const double* trace_part, int ntrace) {
+        if (!trace_part) {
+            const int g = grid_elems((size_t)K);
+            hipLaunchKernelGGL((k_tracepart<T>), dim3(g), dim3(BLOCK), 0, st, K, indptr, col, val, trace_own.p);
+            trace_part = trace_own.p;
+            ntrace = g;
+        }
+        hipLaunchKernelGGL((k_rowabs<T>), dim3(nblk), dim3(BLOCK), 0, st, K, indptr, col, val, ascale, trace_part, ntrace, rho_part.p);
+        hipLaunchKernelGGL(k_plan, dim3(1), dim3(BLOCK), 0, st, K, method, max_order, tol, ascale, rho_part.p, nblk, trace_part, ntrace, plan_d.p);
+        MMW_HIP(hipGetLastError());
+        MMW_HIP(hipMemcpyAsync(plan_h, plan_d.p, sizeof(ExpmPlan), hipMemcpyDeviceToHost, st));
+        MMW_HIP(hipStreamSynchronize(st));
+        last = *plan_h;
+        if (last.overflow) return fail(MMW_ERR_STATE, "expm: the one-norm of the matrix is too large for max_order (raise max_order)");
+        return MMW_OK;
+    }
+
+    // out = exp(ascale*A) * start_block().  `out` must not alias the engine's blocks.
+    int apply(T* out, double ascale, const double* trace_part = nullptr, int ntrace = 0) {
+        MMW_TRY(make_plan(ascale, trace_part, ntrace));
+        const int m = last.m, nsub = last.nsub;
+        const int Dpad = lay.Dpad;
+        const int gcol = (Dpad + 63) / 64;
+        const int gel = grid_elems(bs);
+        const size_t shcol = (size_t)BLOCK * sizeof(double);
+        for (int sub = 0; sub < nsub; ++sub) {
+            if (sub > 0) {
+                hipLaunchKernelGGL((k_copy<T>), dim3(gel), dim3(BLOCK), 0, st, bs, out, U.p);
+            }
+            if (method == MMW_EXPM_LANCZOS) {
+                LanczosScalars S = scalars();
+                const int gr = grid_rows(K * 4);  // k_colsq / k_lz_update stride rows by workgroup
+                hipLaunchKernelGGL((k_colsq<T>), dim3(gr), dim3(BLOCK), shcol, st, K, Dpad, U.p, partial.p);
+                MMW_TRY(colreduce(gr));
+                hipLaunchKernelGGL(k_lz_init, dim3(gcol), dim3(64), 0, st, Dpad, colsum.p, S);
+                for (int j = 1; j <= m; ++j) {
+                    MMW_TRY((launch_spmm<SPMM_LANCZOS>(block(j - 1), Tm.p, nullptr, ascale, 0.0, 1.0)));
+                    MMW_TRY(colreduce(nblk));
+                    hipLaunchKernelGGL(k_lz_alpha, dim3(gcol), dim3(64), 0, st, Dpad, j, colsum.p, S);
+                    if (j < m) {
+                        hipLaunchKernelGGL((k_lz_update<T>), dim3(gr), dim3(BLOCK), shcol, st, K, Dpad, j, Tm.p, block(j - 1),
+                                           j > 1 ? block(j - 2) : block(j - 1), block(j), S, partial.p);
+                        MMW_TRY(colreduce(gr));
+                        const double eps = sizeof(T) == 4 ? 1e-6 : 1e-14;
+                        hipLaunchKernelGGL(k_lz_beta, dim3(gcol), dim3(64), 0, st, Dpad, j, eps, colsum.p, S);
+                    }
+                }
+                hipLaunchKernelGGL(k_lz_texp, dim3(gcol), dim3(64), 0, st, Dpad, m, 1.0 / nsub, S);
+                hipLaunchKernelGGL((k_lz_combine<T>), dim3(gel), dim3(BLOCK), 0, st, K, Dpad, m, U.p, bs, S.coef, out);
+            } else {
+                hipLaunchKernelGGL((k_copy<T>), dim3(gel), dim3(BLOCK), 0, st, bs, U.p, out);
+                for (int k = 1; k <= m; ++k) {
+                    T* in = k == 1 ? U.p : block((k - 1) % 2 + 1);
+                    T* o = block(k % 2 + 1);
+                    MMW_TRY((launch_spmm<SPMM_TAYLOR>(in, o, out, ascale / nsub, last.mu / nsub, 1.0 / k)));
+                }
+                hipLaunchKernelGGL((k_scale<T>), dim3(gel), dim3(BLOCK), 0, st, bs, out, std::exp(last.mu / nsub));
+            }
+            MMW_HIP(hipGetLastError());
+        }
+        return MMW_OK;
+    }
+};
+
+}  // namespace mmw

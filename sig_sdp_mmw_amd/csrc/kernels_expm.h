@@ -1,0 +1,458 @@
+// Device kernels for the action of exp(A) on a dense K x D block (A symmetric, fixed CSR pattern):
+// the CSR SpMM, the per-column Lanczos recurrences, the small tridiagonal exponentials and the
+// shifted-Taylor variant.  Replaces scipy.sparse.linalg.expm_multiply as called from
+// mmw.expm_half_randsk (sim_src/alg/mmw.py:224-229).
+//
+// Block layout: row-major [K, Dpad], Dpad a multiple of the 16-byte vector width.  A row is covered by
+// LPR = Dpad / VEC lanes, each holding VEC consecutive columns (one 16-B load).  When LPR <= 32 it is a
+// power of two and one wavefront processes G = 64/LPR nonzeros of a matrix row at a time (one lane
+// group per nonzero: every gather is a fully coalesced LPR*16-byte row segment); for wider blocks one
+// lane covers NCH chunks 64 lanes apart.  All HBM-bound: ~0.2-2 flop/byte, so no MFMA here.
+#pragma once
+#include "device_utils.h"
+
+namespace mmw {
+
+struct BlockLayout {
+    int D, Dpad, LPR, G, NCH;
+};
+
+struct ExpmPlan {      // written by k_plan, read by every expm kernel
+    double rho;        // bound on || A - mu I ||_1
+    double mu;         // trace(A)/K
+    int m;             // Krylov order / Taylor degree per substep
+    int nsub;          // substeps (time stepping exp(A) = exp(A/nsub)^nsub)
+    int overflow;      // 1 when max_order could not meet tol
+    int pad;
+};
+
+enum { SPMM_PLAIN = 0, SPMM_LANCZOS = 1, SPMM_TAYLOR = 2 };
+
+// Out = ascale * A * U (+ mode-specific fused epilogue).  One wavefront per matrix row, grid-stride.
+//   SPMM_LANCZOS: also partial[block][col] = sum_rows U[row,col] * Out[row,col]   (alpha numerators)
+//   SPMM_TAYLOR : Out = (ascale*A*U - shift*U) * inv_k ;  F += Out                (one Taylor term)
+template <typename T, int NCH, int MODE>
+__global__ __launch_bounds__(BLOCK) void k_spmm(int K, BlockLayout lay, const int* __restrict__ indptr,
+                                                const int* __restrict__ col, const T* __restrict__ val,
+                                                const T* __restrict__ U, T* __restrict__ Out, T* __restrict__ F,
+                                                double ascale, double shift, double inv_k,
+                                                double* __restrict__ partial) {
+    constexpr int VEC = V16<T>::N;
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const int LPR = lay.LPR, G = lay.G, Dpad = lay.Dpad;
+    const int g = (NCH == 1) ? lane / LPR : 0;
+    const int lig = (NCH == 1) ? lane - g * LPR : lane;
+    const bool active = g < G;
+    double dot[NCH][VEC];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) dot[c][v] = 0.0;
+
+    for (int row = blockIdx.x * WAVES_PER_BLOCK + wib; row < K; row += gridDim.x * WAVES_PER_BLOCK) {
+        T acc[NCH][VEC];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[c][v] = T(0);
+        const int beg = indptr[row], end = indptr[row + 1];
+        if (active) {
+            int i = beg + g;
+            // 4 independent gathers in flight per lane group
+            for (; i + 3 * G < end; i += 4 * G) {
+                int cc[4];
+                T vv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    cc[u] = col[i + u * G];
+                    vv[u] = val[i + u * G];
+                }
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if (lig + 64 * c < LPR) {
+                        T x[4][VEC];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) load16(U + (size_t)cc[u] * Dpad + (size_t)(lig + 64 * c) * VEC, x[u]);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v) acc[c][v] += vv[u] * x[u][v];
+                    }
+                }
+            }
+            for (; i < end; i += G) {
+                const int cc = col[i];
+                const T vv = val[i];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if (lig + 64 * c < LPR) {
+                        T x[VEC];
+                        load16(U + (size_t)cc * Dpad + (size_t)(lig + 64 * c) * VEC, x);
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) acc[c][v] += vv * x[v];
+                    }
+                }
+            }
+        }
+        if (NCH == 1 && G > 1) {  // fold the G lane groups (LPR is a power of two here)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+                for (int o = LPR; o < WAVE; o <<= 1) acc[0][v] += __shfl_xor(acc[0][v], o, WAVE);
+        }
+        if (g == 0) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (lig + 64 * c < LPR) {
+                    const size_t off = (size_t)row * Dpad + (size_t)(lig + 64 * c) * VEC;
+                    T o[VEC];
+                    if (MODE == SPMM_PLAIN) {
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) o[v] = (T)(ascale * (double)acc[c][v]);
+                    } else if (MODE == SPMM_LANCZOS) {
+                        T u[VEC];
+                        load16(U + off, u);
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) {
+                            o[v] = (T)(ascale * (double)acc[c][v]);
+                            dot[c][v] += (double)u[v] * (double)o[v];
+                        }
+                    } else {
+                        T u[VEC], f[VEC];
+                        load16(U + off, u);
+                        load16(F + off, f);
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) {
+                            o[v] = (T)((ascale * (double)acc[c][v] - shift * (double)u[v]) * inv_k);
+                            f[v] += o[v];
+                        }
+                        store16(F + off, f);
+                    }
+                    store16(Out + off, o);
+                }
+            }
+        }
+    }
+    if (MODE == SPMM_LANCZOS) {
+        extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+        double* sh = reinterpret_cast<double*>(smem_raw);  // [WAVES_PER_BLOCK][Dpad]
+        if (g == 0) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+                if (lig + 64 * c < LPR)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) sh[wib * Dpad + (lig + 64 * c) * VEC + v] = dot[c][v];
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < Dpad; c += BLOCK) {
+            double s = 0.0;
+            for (int w = 0; w < WAVES_PER_BLOCK; ++w) s += sh[w * Dpad + c];
+            partial[(size_t)blockIdx.x * Dpad + c] = s;
+        }
+    }
+}
+
+// Column sums of squares of a block: partial[block][col] = sum over the block's rows of X^2.
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_colsq(int K, int Dpad, const T* __restrict__ X, double* __restrict__ partial) {
+    // thread t owns column (t % Dpad) for rows t / Dpad + n * rows_per_pass
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* sh = reinterpret_cast<double*>(smem_raw);  // [BLOCK]
+    const int rpp = BLOCK / Dpad > 0 ? BLOCK / Dpad : 1;
+    for (int c0 = 0; c0 < Dpad; c0 += BLOCK) {
+        const int c = c0 + (Dpad >= BLOCK ? threadIdx.x : threadIdx.x % Dpad);
+        const int r0 = Dpad >= BLOCK ? 0 : threadIdx.x / Dpad;
+        double s = 0.0;
+        if (c < Dpad && r0 < rpp)
+            for (int row = blockIdx.x * rpp + r0; row < K; row += gridDim.x * rpp) {
+                const double x = (double)X[(size_t)row * Dpad + c];
+                s += x * x;
+            }
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        if (Dpad >= BLOCK) {
+            if (c < Dpad) partial[(size_t)blockIdx.x * Dpad + c] = s;
+        } else if (threadIdx.x < Dpad) {
+            double t = 0.0;
+            for (int r = 0; r < rpp; ++r) t += sh[r * Dpad + threadIdx.x];
+            partial[(size_t)blockIdx.x * Dpad + threadIdx.x] = t;
+        }
+        __syncthreads();
+    }
+}
+
+// out[col] = sum_b partial[b][col]; one workgroup per 16 columns, 16 threads per column.
+__global__ __launch_bounds__(BLOCK) void k_colreduce(int nb, int Dpad, const double* __restrict__ partial,
+                                                      double* __restrict__ out) {
+    __shared__ double sh[BLOCK];
+    const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;  // 16 cols x 16 parts
+    const int c = blockIdx.x * 16 + cl;
+    double s = 0.0;
+    if (c < Dpad)
+        for (int b = part; b < nb; b += 16) s += partial[(size_t)b * Dpad + c];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (part == 0 && c < Dpad) {
+        double t = 0.0;
+        for (int p = 0; p < 16; ++p) t += sh[p * 16 + cl];
+        out[c] = t;
+    }
+}
+
+// Lanczos scalars, per column c (all arrays [MAX_ORDER+2][Dpad], index j = Lanczos step starting at 1):
+//   beta[0] = ||b_c||, sinv[j] = 1/beta[j-1] (0 when the Krylov space is exhausted), alpha[j].
+struct LanczosScalars {
+    double* alpha;
+    double* beta;
+    double* sinv;
+    double* coef;  // [MAX_ORDER+1][Dpad]: y = sum_j coef[j] U_j
+};
+
+// after k_colsq of the start block: beta0, sinv1
+__global__ void k_lz_init(int Dpad, const double* __restrict__ colsq, LanczosScalars S) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Dpad) return;
+    const double b = sqrt(colsq[c]);
+    S.beta[c] = b;
+    S.sinv[1 * Dpad + c] = b > 0.0 ? 1.0 / b : 0.0;
+}
+// after SpMM step j: alpha_j = sinv_j^2 * (U_j . A U_j)
+__global__ void k_lz_alpha(int Dpad, int j, const double* __restrict__ dotsum, LanczosScalars S) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Dpad) return;
+    const double s = S.sinv[j * Dpad + c];
+    S.alpha[j * Dpad + c] = s * s * dotsum[c];
+}
+// U_{j+1} = sinv_j * t - alpha_j sinv_j U_j - beta_{j-1} sinv_{j-1} U_{j-1};  partial col sums of U_{j+1}^2
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_lz_update(int K, int Dpad, int j, const T* __restrict__ Tm, const T* __restrict__ Uj,
+                                                     const T* __restrict__ Ujm1, T* __restrict__ Unext, LanczosScalars S,
+                                                     double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* sh = reinterpret_cast<double*>(smem_raw);  // [BLOCK]
+    const int rpp = BLOCK / Dpad > 0 ? BLOCK / Dpad : 1;
+    for (int c0 = 0; c0 < Dpad; c0 += BLOCK) {
+        const int c = c0 + (Dpad >= BLOCK ? threadIdx.x : threadIdx.x % Dpad);
+        const int r0 = Dpad >= BLOCK ? 0 : threadIdx.x / Dpad;
+        double s = 0.0;
+        if (c < Dpad && r0 < rpp) {
+            const double sj = S.sinv[j * Dpad + c];
+            const double c2 = S.alpha[j * Dpad + c] * sj;
+            const double c3 = j > 1 ? S.beta[(j - 1) * Dpad + c] * S.sinv[(j - 1) * Dpad + c] : 0.0;
+            for (int row = blockIdx.x * rpp + r0; row < K; row += gridDim.x * rpp) {
+                const size_t o = (size_t)row * Dpad + c;
+                double w = sj * (double)Tm[o] - c2 * (double)Uj[o];
+                if (j > 1) w -= c3 * (double)Ujm1[o];
+                const T wt = (T)w;
+                Unext[o] = wt;
+                s += (double)wt * (double)wt;
+            }
+        }
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        if (Dpad >= BLOCK) {
+            if (c < Dpad) partial[(size_t)blockIdx.x * Dpad + c] = s;
+        } else if (threadIdx.x < Dpad) {
+            double t = 0.0;
+            for (int r = 0; r < rpp; ++r) t += sh[r * Dpad + threadIdx.x];
+            partial[(size_t)blockIdx.x * Dpad + threadIdx.x] = t;
+        }
+        __syncthreads();
+    }
+}
+// beta_j = ||U_{j+1}||, sinv_{j+1}.  A column whose new vector is at rounding level relative to the
+// recurrence terms has exhausted its Krylov space: it is frozen (all later vectors zero).
+__global__ void k_lz_beta(int Dpad, int j, double breakdown_eps, const double* __restrict__ colsq, LanczosScalars S) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Dpad) return;
+    const double b = sqrt(colsq[c]);
+    const double scale = fabs(S.alpha[j * Dpad + c]) + (j > 1 ? S.beta[(j - 1) * Dpad + c] : 0.0);
+    const bool dead = S.sinv[j * Dpad + c] == 0.0 || !(b > breakdown_eps * scale) || !(b > 0.0);
+    S.beta[j * Dpad + c] = dead ? 0.0 : b;
+    S.sinv[(j + 1) * Dpad + c] = dead ? 0.0 : 1.0 / b;
+}
+// per column: g = exp(T_m / nsub) e_1 for the m x m tridiagonal T (alpha_1..m, beta_1..m-1);
+// coef[j] = beta0 * g_j * sinv_j  so that  y = sum_j coef[j] U_j.
+// exp(T) e_1 by a scaled Taylor series on the m-vector (||T|| is small here; squaring by repeated
+// application keeps it valid for any norm).
+__global__ void k_lz_texp(int Dpad, int m, double inv_nsub, LanczosScalars S) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Dpad) return;
+    double a[MAX_ORDER], b[MAX_ORDER], g[MAX_ORDER], t[MAX_ORDER], f[MAX_ORDER];
+    double nrm = 0.0, mu = 0.0;
+    int mm = m;
+    for (int j = 0; j < m; ++j) {
+        a[j] = S.alpha[(j + 1) * Dpad + c] * inv_nsub;
+        b[j] = j + 1 < m ? S.beta[(j + 1) * Dpad + c] * inv_nsub : 0.0;
+    }
+    for (int j = 0; j + 1 < m; ++j)
+        if (b[j] == 0.0) {  // breakdown: the leading block is exact
+            mm = j + 1;
+            break;
+        }
+    for (int j = 0; j < mm; ++j) mu += a[j];
+    mu /= mm;
+    for (int j = 0; j < mm; ++j) {
+        a[j] -= mu;
+        const double r = fabs(a[j]) + (j > 0 ? fabs(b[j - 1]) : 0.0) + (j + 1 < mm ? fabs(b[j]) : 0.0);
+        nrm = r > nrm ? r : nrm;
+    }
+    int sq = 1;
+    while (nrm / sq > 0.5) sq *= 2;
+    const double isq = 1.0 / sq;
+    for (int j = 0; j < mm; ++j) g[j] = j == 0 ? 1.0 : 0.0;
+    for (int rep = 0; rep < sq; ++rep) {  // g <- exp(T/sq) g
+        for (int j = 0; j < mm; ++j) {
+            t[j] = g[j];
+            f[j] = g[j];
+        }
+        for (int k = 1; k <= 24; ++k) {
+            double tn[MAX_ORDER];
+            double big = 0.0;
+            for (int j = 0; j < mm; ++j) {
+                double v = a[j] * t[j];
+                if (j > 0) v += b[j - 1] * t[j - 1];
+                if (j + 1 < mm) v += b[j] * t[j + 1];
+                tn[j] = v * isq / k;
+                big = fabs(tn[j]) > big ? fabs(tn[j]) : big;
+            }
+            for (int j = 0; j < mm; ++j) {
+                t[j] = tn[j];
+                f[j] += tn[j];
+            }
+            if (big < 1e-18) break;
+        }
+        for (int j = 0; j < mm; ++j) g[j] = f[j];
+    }
+    const double e = exp(mu) * S.beta[c];
+    for (int j = 0; j < m; ++j) S.coef[(j + 1) * Dpad + c] = j < mm ? e * g[j] * S.sinv[(j + 1) * Dpad + c] : 0.0;
+}
+// y[row,:] = sum_{j=1..m} coef[j][:] * U_j[row,:]  (U_j = Ubase + (j-1)*stride)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_lz_combine(int K, int Dpad, int m, const T* __restrict__ Ubase, size_t stride,
+                                                      const double* __restrict__ coef, T* __restrict__ Yout) {
+    const size_t n = (size_t)K * Dpad;
+    for (size_t o = (size_t)blockIdx.x * BLOCK + threadIdx.x; o < n; o += (size_t)gridDim.x * BLOCK) {
+        const int c = (int)(o % Dpad);
+        double s = 0.0;
+        for (int j = 1; j <= m; ++j) s += coef[j * Dpad + c] * (double)Ubase[(size_t)(j - 1) * stride + o];
+        Yout[o] = (T)s;
+    }
+}
+// y *= scale (Taylor: e^{mu})
+template <typename T> __global__ __launch_bounds__(BLOCK) void k_scale(size_t n, T* __restrict__ y, double scale) {
+    for (size_t o = (size_t)blockIdx.x * BLOCK + threadIdx.x; o < n; o += (size_t)gridDim.x * BLOCK)
+        y[o] = (T)((double)y[o] * scale);
+}
+template <typename T> __global__ __launch_bounds__(BLOCK) void k_copy(size_t n, const T* __restrict__ a, T* __restrict__ b) {
+    for (size_t o = (size_t)blockIdx.x * BLOCK + threadIdx.x; o < n; o += (size_t)gridDim.x * BLOCK) b[o] = a[o];
+}
+// float64 host block [K, D] -> device block [K, Dpad] of T (zero padded)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_import_block(int K, int D, int Dpad, const double* __restrict__ src, T* __restrict__ dst) {
+    const size_t n = (size_t)K * Dpad;
+    for (size_t o = (size_t)blockIdx.x * BLOCK + threadIdx.x; o < n; o += (size_t)gridDim.x * BLOCK) {
+        const int c = (int)(o % Dpad);
+        const size_t r = o / Dpad;
+        dst[o] = c < D ? (T)src[r * D + c] : T(0);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_export_block(int K, int D, int Dpad, const T* __restrict__ src, double* __restrict__ dst) {
+    const size_t n = (size_t)K * D;
+    for (size_t o = (size_t)blockIdx.x * BLOCK + threadIdx.x; o < n; o += (size_t)gridDim.x * BLOCK) {
+        const int c = (int)(o % D);
+        const size_t r = o / D;
+        dst[o] = (double)src[r * Dpad + c];
+    }
+}
+
+// ---- planning: 1-norm bound of A - mu I from the values on a symmetric pattern ----------------
+// partial[block] = max over the block's rows of sum_e |ascale*val[e] - mu*[e is diag]|
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_rowabs(int K, const int* __restrict__ indptr, const int* __restrict__ col,
+                                                  const T* __restrict__ val, double ascale, const double* __restrict__ trace_part,
+                                                  int ntrace, double* __restrict__ partial) {
+    __shared__ double sh[WAVES_PER_BLOCK];
+    // mu from the per-block diagonal sums of the producing kernel (every block re-reduces the same slab)
+    double tr = 0.0;
+    for (int i = threadIdx.x; i < ntrace; i += BLOCK) tr += trace_part[i];
+    tr = block_sum(tr, sh);
+    const double mu = ascale * tr / K;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    double best = 0.0;
+    for (int row = blockIdx.x * WAVES_PER_BLOCK + wib; row < K; row += gridDim.x * WAVES_PER_BLOCK) {
+        double s = 0.0;
+        for (int e = indptr[row] + lane; e < indptr[row + 1]; e += WAVE) {
+            double v = ascale * (double)val[e];
+            if (col[e] == row) v -= mu;
+            s += fabs(v);
+        }
+        s = wave_sum(s);
+        best = s > best ? s : best;
+    }
+    best = block_max(best, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = best;
+}
+// diagonal sums when no producer kernel made them (stand-alone expm)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_tracepart(int K, const int* __restrict__ indptr, const int* __restrict__ col,
+                                                     const T* __restrict__ val, double* __restrict__ partial) {
+    __shared__ double sh[WAVES_PER_BLOCK];
+    double s = 0.0;
+    for (int row = blockIdx.x * BLOCK + threadIdx.x; row < K; row += gridDim.x * BLOCK)
+        for (int e = indptr[row]; e < indptr[row + 1]; ++e)
+            if (col[e] == row) s += (double)val[e];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__host__ __device__ inline int plan_order(int method, double rho, double tol, int max_order) {
+    // smallest m with a remainder bound below tol.  Lanczos (m-dimensional Krylov space): the error is
+    // at most twice the best degree-(m-1) polynomial error on [-rho, rho], bounded by the Chebyshev-shifted
+    // Taylor remainder 2 (rho/2)^m / m! e^{rho};  Taylor degree m: rho^{m+1}/(m+1)! e^{rho}.
+    double term = 1.0;
+    const double er = exp(2.0 * rho);  // also covers the e^{-rho} lower bound on ||exp(A')b|| / ||b||
+    for (int m = 1; m <= max_order; ++m) {
+        if (method == 0) {
+            term *= (rho * 0.5) / m;
+            if (4.0 * term * er <= tol) return m;
+        } else {
+            term *= rho / m;
+            if (term * rho / (m + 1) * er <= tol) return m;
+        }
+    }
+    return -1;
+}
+
+__global__ void k_plan(int K, int method, int max_order, double tol, double ascale, const double* __restrict__ rho_part, int nrho,
+                       const double* __restrict__ trace_part, int ntrace, ExpmPlan* __restrict__ plan) {
+    __shared__ double sh[WAVES_PER_BLOCK];
+    double r = 0.0, tr = 0.0;
+    for (int i = threadIdx.x; i < nrho; i += blockDim.x) r = rho_part[i] > r ? rho_part[i] : r;
+    for (int i = threadIdx.x; i < ntrace; i += blockDim.x) tr += trace_part[i];
+    r = block_max(r, sh);
+    tr = block_sum(tr, sh);
+    if (threadIdx.x == 0) {
+        ExpmPlan p;
+        p.rho = r;
+        p.mu = ascale * tr / K;
+        p.overflow = 0;
+        p.pad = 0;
+        int nsub = 1, m = -1;
+        for (; nsub <= 4096; nsub *= 2) {
+            m = plan_order(method, r / nsub, tol / nsub, max_order);
+            if (m > 0) break;
+        }
+        if (m <= 0) {
+            m = max_order;
+            nsub = 4096;
+            p.overflow = 1;
+        }
+        p.m = m;
+        p.nsub = nsub;
+        *plan = p;
+    }
+}
+
+}  // namespace mmw

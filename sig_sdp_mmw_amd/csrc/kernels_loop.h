@@ -1,0 +1,309 @@
+// Device kernels for the per-iteration MMW phases on the fixed L/X pattern:
+//   DUAL  (sim_src/alg/mmw.py:124-142): violations e(X), e_accu += eta e, Y = softmax(e_accu)
+//   LOSS  (mmw.py:144-170):             L_accu -= eta (LD + LF + LH)
+//   X on the pattern (mmw.py:182-194):  row norms, trace, SDDMM over the edges
+//   averaging (mmw.py:77-78) is folded into the producers of X and Y.
+// Reductions are wavefront shuffles + fixed-order per-block slabs (bitwise reproducible, no atomics).
+#pragma once
+#include "device_utils.h"
+
+namespace mmw {
+
+template <typename T> struct PatternDev {
+    int K, Z, E_asso, C;
+    int nnzL;
+    const int* indptr;
+    const int* col;
+    const int* pid;       // association pair id or -1
+    const int* mirror;
+    const int* diag_pos;
+    const int* asso_pos;
+    const T* sab;         // S_T'[row,col]
+    const T* sba;         // S_T'[col,row]
+    const T* h_max;
+    const T* S_sum;
+    const T* inv_norm_H;  // 1/norm_H
+    const T* cH;          // h_max/K - S_sum/(K Z)
+};
+
+// ---- DUAL, step 1: per row r[k] = sum of off-diagonal X, eD; per pair eF -------------------------
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_dual_rows(PatternDev<T> P, const T* __restrict__ xval, T* __restrict__ rsum,
+                                                     T* __restrict__ e_this) {
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int K = P.K;
+    const double invK = 1.0 / (double)K;
+    for (int row = blockIdx.x * WAVES_PER_BLOCK + wib; row < K; row += gridDim.x * WAVES_PER_BLOCK) {
+        double s = 0.0;
+        const int dp = P.diag_pos[row];
+        for (int e = P.indptr[row] + lane; e < P.indptr[row + 1]; e += WAVE)
+            if (e != dp) s += (double)xval[e];
+        s = wave_sum(s);
+        if (lane == 0) {
+            rsum[row] = (T)s;
+            e_this[row] = (T)(((double)xval[dp] - 1.0) / (1.0 - invK));  // mmw.py:127
+        }
+    }
+    const double Zm1 = (double)(P.Z - 1);
+    const double den = 1.0 / ((double)K * Zm1) + 0.5;  // mmw.py:131
+    for (int p = blockIdx.x * BLOCK + threadIdx.x; p < P.E_asso; p += gridDim.x * BLOCK)
+        e_this[K + p] = (T)(((double)xval[P.asso_pos[p]] + 1.0 / Zm1) / den);
+}
+
+// ---- DUAL, step 2: eH = (S_T' r (Z-1)/Z - (h - S_sum/Z)) / norm_H ; e_accu += eta e ; block max ----
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_dual_h(PatternDev<T> P, const T* __restrict__ rsum, T* __restrict__ e_this,
+                                                  T* __restrict__ e_accu, double eta, double* __restrict__ max_part) {
+    __shared__ double sh[WAVES_PER_BLOCK];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int K = P.K, Z = P.Z;
+    double best = -1e300;
+    const int baseH = K + P.E_asso;
+    for (int row = blockIdx.x * WAVES_PER_BLOCK + wib; row < K; row += gridDim.x * WAVES_PER_BLOCK) {
+        double s = 0.0;
+        for (int e = P.indptr[row] + lane; e < P.indptr[row + 1]; e += WAVE) {
+            const double w = (double)P.sab[e];
+            if (w != 0.0) s += w * (double)rsum[P.col[e]];
+        }
+        s = wave_sum(s);
+        if (lane == 0) {
+            const double eh = (s * (double)(Z - 1) / (double)Z - ((double)P.h_max[row] - (1.0 / (double)Z) * (double)P.S_sum[row])) *
+                              (double)P.inv_norm_H[row];  // mmw.py:134
+            e_this[baseH + row] = (T)eh;
+            const T a = (T)((double)e_accu[baseH + row] + (double)(T)eh * eta);
+            e_accu[baseH + row] = a;
+            best = (double)a > best ? (double)a : best;
+        }
+    }
+    for (int c = blockIdx.x * BLOCK + threadIdx.x; c < baseH; c += gridDim.x * BLOCK) {
+        const T a = (T)((double)e_accu[c] + (double)e_this[c] * eta);
+        e_accu[c] = a;
+        best = (double)a > best ? (double)a : best;
+    }
+    best = block_max(best, sh);
+    if (threadIdx.x == 0) max_part[blockIdx.x] = best;
+}
+
+// ---- softmax pass A: Y <- exp(e_accu - max); per block sums {all, D block, F block, sum_H cH*Y/norm_H}
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_softmax_a(PatternDev<T> P, const T* __restrict__ e_accu, T* __restrict__ Y,
+                                                     const double* __restrict__ max_part, int nmax,
+                                                     double* __restrict__ sum_part /* [4][grid] */) {
+    __shared__ double sh[WAVES_PER_BLOCK];
+    double m = -1e300;
+    for (int i = threadIdx.x; i < nmax; i += BLOCK) m = max_part[i] > m ? max_part[i] : m;
+    m = block_max(m, sh);
+    const int K = P.K, baseH = K + P.E_asso, C = P.C;
+    double sD = 0.0, sF = 0.0, sH = 0.0, sW = 0.0;
+    for (int c = blockIdx.x * BLOCK + threadIdx.x; c < C; c += gridDim.x * BLOCK) {
+        const T ex = (T)exp((double)e_accu[c] - m);
+        Y[c] = ex;
+        if (c < K) sD += (double)ex;
+        else if (c < baseH) sF += (double)ex;
+        else {
+            sH += (double)ex;
+            sW += (double)P.cH[c - baseH] * (double)ex * (double)P.inv_norm_H[c - baseH];
+        }
+    }
+    sD = block_sum(sD, sh);
+    sF = block_sum(sF, sh);
+    sH = block_sum(sH, sh);
+    sW = block_sum(sW, sh);
+    if (threadIdx.x == 0) {
+        sum_part[0 * gridDim.x + blockIdx.x] = sD;
+        sum_part[1 * gridDim.x + blockIdx.x] = sF;
+        sum_part[2 * gridDim.x + blockIdx.x] = sH;
+        sum_part[3 * gridDim.x + blockIdx.x] = sW;
+    }
+}
+// ---- softmax pass B: Y /= total; yavg += Y; scalars for the loss {sumYD, sumYF, sum cH YH/normH}
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_softmax_b(int C, T* __restrict__ Y, T* __restrict__ yavg, int accumulate,
+                                                     const double* __restrict__ sum_part, int npart,
+                                                     double* __restrict__ scal /* [4] */) {
+    __shared__ double sh[WAVES_PER_BLOCK];
+    double s[4];
+    for (int q = 0; q < 4; ++q) {
+        double t = 0.0;
+        for (int i = threadIdx.x; i < npart; i += BLOCK) t += sum_part[q * npart + i];
+        s[q] = block_sum(t, sh);
+    }
+    const double total = s[0] + s[1] + s[2];
+    for (int c = blockIdx.x * BLOCK + threadIdx.x; c < C; c += gridDim.x * BLOCK) {
+        const T y = (T)((double)Y[c] / total);
+        Y[c] = y;
+        if (accumulate) yavg[c] += y;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        scal[0] = s[0] / total;
+        scal[1] = s[1] / total;
+        scal[2] = s[3] / total;
+        scal[3] = total;
+    }
+}
+
+// ---- LOSS: lval -= eta * (LD + LF + LH) on the pattern; per-block partial of the diagonal sum ------
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_loss(PatternDev<T> P, const T* __restrict__ Y, const double* __restrict__ scal,
+                                                T* __restrict__ lval, double eta, double* __restrict__ trace_part) {
+    __shared__ double sh[WAVES_PER_BLOCK];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int K = P.K, Z = P.Z, baseF = K, baseH = K + P.E_asso;
+    const double invK = 1.0 / (double)K, Zm1 = (double)(Z - 1);
+    const double cF = 0.5 + 1.0 / ((double)K * Zm1);
+    const double sumYD = scal[0], sumYF = scal[1], sumW = scal[2];
+    const double dconst = -(sumYD * invK) / (1.0 - invK) + (sumYF / ((double)K * Zm1)) / cF - sumW;
+    const double gscale = Zm1 / (double)(2 * Z);
+    double tr = 0.0;
+    for (int row = blockIdx.x * WAVES_PER_BLOCK + wib; row < K; row += gridDim.x * WAVES_PER_BLOCK) {
+        const double w_row = (double)Y[baseH + row] * (double)P.inv_norm_H[row];
+        for (int e = P.indptr[row] + lane; e < P.indptr[row + 1]; e += WAVE) {
+            const int c = P.col[e];
+            double add;
+            if (c == row) {
+                add = (double)Y[row] / (1.0 - invK) + dconst;
+            } else if (P.pid[e] >= 0) {
+                add = ((double)Y[baseF + P.pid[e]] * 0.5) / cF;
+            } else {
+                const double w_col = (double)Y[baseH + c] * (double)P.inv_norm_H[c];
+                add = ((double)P.sab[e] * w_col + (double)P.sba[e] * w_row) * gscale;  // column-scaled S_T' symmetrised
+            }
+            const T nv = (T)((double)lval[e] - eta * add);
+            lval[e] = nv;
+            if (c == row) tr += (double)nv;
+        }
+    }
+    tr = block_sum(tr, sh);
+    if (threadIdx.x == 0) trace_part[blockIdx.x] = tr;
+}
+
+// ---- row norms of X_half: d[row] = ||y_row||^2, per-block partial sums of d -----------------------
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_rownorm2(int K, int Dpad, const T* __restrict__ Yb, T* __restrict__ d,
+                                                    double* __restrict__ part) {
+    __shared__ double sh[WAVES_PER_BLOCK];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    double tot = 0.0;
+    for (int row = blockIdx.x * WAVES_PER_BLOCK + wib; row < K; row += gridDim.x * WAVES_PER_BLOCK) {
+        double s = 0.0;
+        for (int c = lane; c < Dpad; c += WAVE) {
+            const double x = (double)Yb[(size_t)row * Dpad + c];
+            s += x * x;
+        }
+        s = wave_sum(s);
+        if (lane == 0) {
+            d[row] = (T)s;
+            tot += (double)(T)s;
+        }
+    }
+    tot = block_sum(tot, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+// ---- SDDMM on the edges: X[a,b] = <y_a, y_b> / tr for b > a, mirrored; diagonal d/tr; xavg += X ----
+template <typename T, int NCH>
+__global__ __launch_bounds__(BLOCK) void k_sddmm(PatternDev<T> P, int Dpad, int LPR, int G, const T* __restrict__ Yb,
+                                                 const T* __restrict__ d, const double* __restrict__ tr_part, int ntr,
+                                                 T* __restrict__ xval, T* __restrict__ xavg, int accumulate) {
+    constexpr int VEC = V16<T>::N;
+    __shared__ double sh[WAVES_PER_BLOCK];
+    double t = 0.0;
+    for (int i = threadIdx.x; i < ntr; i += BLOCK) t += tr_part[i];
+    t = block_sum(t, sh);
+    const double tr = t / (double)P.K;  // mmw.py:184
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int g = (NCH == 1) ? lane / LPR : 0;
+    const int lig = (NCH == 1) ? lane - g * LPR : lane;
+    const bool active = g < G;
+    for (int row = blockIdx.x * WAVES_PER_BLOCK + wib; row < P.K; row += gridDim.x * WAVES_PER_BLOCK) {
+        T ya[NCH][VEC];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) ya[c][v] = T(0);
+            if (active && lig + 64 * c < LPR) load16(Yb + (size_t)row * Dpad + (size_t)(lig + 64 * c) * VEC, ya[c]);
+        }
+        const int dp = P.diag_pos[row];
+        const int end = P.indptr[row + 1];
+        if (lane == 0) {
+            const T xd = (T)((double)d[row] / tr);
+            xval[dp] = xd;
+            if (accumulate) xavg[dp] += xd;
+        }
+        // entries right of the diagonal are the upper-triangular edges of this row
+        for (int e0 = dp + 1; e0 < end; e0 += G) {
+            const int e = e0 + g;
+            double s = 0.0;
+            if (active && e < end) {
+                const int b = P.col[e];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+                    if (lig + 64 * c < LPR) {
+                        T yb[VEC];
+                        load16(Yb + (size_t)b * Dpad + (size_t)(lig + 64 * c) * VEC, yb);
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) s += (double)ya[c][v] * (double)yb[v];
+                    }
+            }
+            if (NCH == 1) s = group_sum(s, LPR);  // LPR is a power of two (or 64) when NCH == 1
+            else s = wave_sum(s);
+            if (active && e < end && lig == 0) {
+                const T x = (T)(s / tr);
+                const int me = P.mirror[e];
+                xval[e] = x;
+                xval[me] = x;
+                if (accumulate) {
+                    xavg[e] += x;
+                    xavg[me] += x;
+                }
+            }
+        }
+    }
+}
+
+// ---- on-device Gaussian sketch: rows of unit 2-norm (mmw.py:226-227) -----------------------------
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_sketch_rng(int K, int D, int Dpad, uint64_t seed, uint32_t iter, T* __restrict__ R) {
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    for (int row = blockIdx.x * WAVES_PER_BLOCK + wib; row < K; row += gridDim.x * WAVES_PER_BLOCK) {
+        double ss = 0.0;
+        // each lane produces pairs of columns (2p, 2p+1)
+        for (int p = lane; 2 * p < Dpad; p += WAVE) {
+            uint32_t w[4];
+            philox4x32_10((uint32_t)row, (uint32_t)p, iter, 0x4d4d5753u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+            double n0, n1;
+            box_muller(w, n0, n1);
+            if (2 * p >= D) n0 = 0.0;
+            if (2 * p + 1 >= D) n1 = 0.0;
+            ss += n0 * n0 + n1 * n1;
+        }
+        ss = wave_sum(ss);
+        const double inv = ss > 0.0 ? 1.0 / sqrt(ss) : 0.0;
+        for (int p = lane; 2 * p < Dpad; p += WAVE) {
+            uint32_t w[4];
+            philox4x32_10((uint32_t)row, (uint32_t)p, iter, 0x4d4d5753u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+            double n0, n1;
+            box_muller(w, n0, n1);
+            if (2 * p >= D) n0 = 0.0;
+            if (2 * p + 1 >= D) n1 = 0.0;
+            R[(size_t)row * Dpad + 2 * p] = (T)(n0 * inv);
+            if (2 * p + 1 < Dpad) R[(size_t)row * Dpad + 2 * p + 1] = (T)(n1 * inv);
+        }
+    }
+}
+
+template <typename T> __global__ __launch_bounds__(BLOCK) void k_fill(size_t n, T* __restrict__ a, T v) {
+    for (size_t o = (size_t)blockIdx.x * BLOCK + threadIdx.x; o < n; o += (size_t)gridDim.x * BLOCK) a[o] = v;
+}
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_set_identity(int K, const int* __restrict__ diag_pos, T* __restrict__ xval, T* __restrict__ xavg) {
+    for (int k = blockIdx.x * BLOCK + threadIdx.x; k < K; k += gridDim.x * BLOCK) {
+        xval[diag_pos[k]] = T(1);
+        xavg[diag_pos[k]] = T(1);
+    }
+}
+template <typename T> __global__ __launch_bounds__(BLOCK) void k_to_f64(size_t n, const T* __restrict__ a, double* __restrict__ b) {
+    for (size_t o = (size_t)blockIdx.x * BLOCK + threadIdx.x; o < n; o += (size_t)gridDim.x * BLOCK) b[o] = (double)a[o];
+}
+
+}  // namespace mmw

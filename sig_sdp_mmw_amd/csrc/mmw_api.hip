@@ -1,0 +1,467 @@
+// C-ABI of the MI355X MMW hot path (include/mmw_hip.h) and the device-resident solver behind it.
+#include <chrono>
+#include <cstring>
+#include <memory>
+
+#include "expm_engine.h"
+#include "kernels_loop.h"
+#include "pattern.h"
+#include "runtime.h"
+#include "solver_extras.h"
+
+using namespace mmw;
+
+struct mmw_solver {
+    virtual ~mmw_solver() {}
+    virtual int sizes(int64_t out[10]) = 0;
+    virtual int set_expm(int method, int max_order, double tol) = 0;
+    virtual int set_timing(int enabled) = 0;
+    virtual int reset(int32_t nit) = 0;
+    virtual int iterate(int32_t n, const double* randv, uint64_t seed) = 0;
+    virtual int sync() = 0;
+    virtual int read_f64(int which, double* out, int64_t n) = 0;
+    virtual int read_i32(int which, int32_t* out, int64_t n) = 0;
+    virtual int gap(double out[3]) = 0;
+    virtual int factor(int32_t rank, double* out, uint64_t seed) = 0;
+    virtual int round(int32_t Zr, int32_t Dp, const double* gX, int32_t nbatch, const double* randv, int32_t* z_out,
+                      int32_t* rem_out) = 0;
+};
+
+namespace {
+
+template <typename T> struct Solver final : mmw_solver {
+    int device = 0;
+    bool host_only = false;
+    hipStream_t st = nullptr;
+    HostPattern H;
+    int K = 0, Z = 0, D = 0, rank_radio = 2, nit = 0, iter = 0;
+    double eta = 0.1;
+    bool timing = false;
+    // pattern on the device
+    DevBuf<int> d_indptr, d_col, d_pid, d_mirror, d_diag, d_apos;
+    DevBuf<T> d_sab, d_sba, d_h, d_ssum, d_invn, d_cH;
+    // iterate state
+    DevBuf<T> lval, xval, xavg, Y, yavg, e_accu, e_this, rsum, Xh, drow;
+    DevBuf<double> max_part, sum_part, scal, trace_part, tr_part, stage64, out64;
+    ExpmEngine<T> eng;
+    Extras<T> extras;
+    std::vector<hipEvent_t> events;  // 4 per timed iteration
+    std::vector<double> phase_us;
+    uint64_t last_seed = 0;
+    bool last_was_rng = false;
+
+    ~Solver() override {
+        if (host_only) return;
+        (void)hipSetDevice(device);
+        for (auto e : events) (void)hipEventDestroy(e);
+        if (st) (void)hipStreamDestroy(st);
+    }
+
+    PatternDev<T> pat() const {
+        PatternDev<T> P;
+        P.K = K; P.Z = Z; P.E_asso = (int)H.E_asso(); P.C = (int)H.C(); P.nnzL = (int)H.nnzL();
+        P.indptr = d_indptr.p; P.col = d_col.p; P.pid = d_pid.p; P.mirror = d_mirror.p; P.diag_pos = d_diag.p;
+        P.asso_pos = d_apos.p; P.sab = d_sab.p; P.sba = d_sba.p; P.h_max = d_h.p; P.S_sum = d_ssum.p;
+        P.inv_norm_H = d_invn.p; P.cH = d_cH.p;
+        return P;
+    }
+
+    int init(int dev, int32_t K_, int32_t Z_, int32_t rr, double eta_, int32_t nit_, const int32_t* Sp, const int32_t* Si,
+             const double* Sx, const int32_t* Qp, const int32_t* Qi, const double* Qx, const double* h) {
+        device = dev;
+        std::string err = build_pattern(H, K_, Z_, Sp, Si, Sx, Qp, Qi, Qx, h);
+        if (!err.empty()) return fail(MMW_ERR_ARG, "mmw_create: " + err);
+        K = K_; Z = Z_; rank_radio = rr; eta = eta_; nit = nit_;
+        D = Z * rank_radio;
+        if (host_only) {  // device == -1: pattern inspection only (CPU tests of the host logic)
+            std::string lerr;
+            if (make_layout(D, V16<T>::N, eng.lay, lerr) != MMW_OK) return fail(MMW_ERR_ARG, lerr);
+            return MMW_OK;
+        }
+        MMW_HIP(hipSetDevice(device));
+        MMW_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        MMW_TRY(d_indptr.upload(H.l_indptr, st));
+        MMW_TRY(d_col.upload(H.l_indices, st));
+        MMW_TRY(d_pid.upload(H.pid, st));
+        MMW_TRY(d_mirror.upload(H.mirror, st));
+        MMW_TRY(d_diag.upload(H.diag_pos, st));
+        MMW_TRY(d_apos.upload(H.asso_pos, st));
+        MMW_TRY(d_sab.upload_cast(H.sab, st));
+        MMW_TRY(d_sba.upload_cast(H.sba, st));
+        MMW_TRY(d_h.upload_cast(H.h_max, st));
+        MMW_TRY(d_ssum.upload_cast(H.S_sum, st));
+        std::vector<double> invn(K);
+        for (int k = 0; k < K; ++k) invn[k] = 1.0 / H.norm_H[k];
+        MMW_TRY(d_invn.upload_cast(invn, st));
+        MMW_TRY(d_cH.upload_cast(H.cH, st));
+        const size_t nnz = (size_t)H.nnzL(), C = (size_t)H.C();
+        MMW_TRY(lval.alloc(nnz)); MMW_TRY(xval.alloc(nnz)); MMW_TRY(xavg.alloc(nnz));
+        MMW_TRY(Y.alloc(C)); MMW_TRY(yavg.alloc(C)); MMW_TRY(e_accu.alloc(C)); MMW_TRY(e_this.alloc(C));
+        MMW_TRY(rsum.alloc(K)); MMW_TRY(drow.alloc(K));
+        MMW_TRY(max_part.alloc(MAX_PART)); MMW_TRY(sum_part.alloc(4 * 2048)); MMW_TRY(scal.alloc(4));
+        MMW_TRY(trace_part.alloc(MAX_PART)); MMW_TRY(tr_part.alloc(MAX_PART));
+        MMW_TRY(eng.init(st, K, D, d_indptr.p, d_col.p, lval.p));
+        eng.max_order = 12;
+        eng.tol = sizeof(T) == 4 ? 1e-6 : 1e-9;
+        MMW_TRY(Xh.alloc(eng.bs));
+        size_t big = std::max(std::max(nnz, C), eng.bs);
+        MMW_TRY(out64.alloc(big));
+        MMW_TRY(stage64.alloc((size_t)K * D));
+        MMW_HIP(hipStreamSynchronize(st));
+        MMW_TRY(extras.init(this->st, &H, K));
+        return reset(nit);
+    }
+
+    int sizes(int64_t out[10]) override {
+        out[0] = K; out[1] = Z; out[2] = D; out[3] = eng.lay.Dpad; out[4] = H.nnzL(); out[5] = H.nnzST();
+        out[6] = H.E_gain(); out[7] = H.E_asso(); out[8] = H.C(); out[9] = iter;
+        return MMW_OK;
+    }
+    int set_expm(int method, int max_order, double tol) override {
+        if (method != MMW_EXPM_LANCZOS && method != MMW_EXPM_TAYLOR) return fail(MMW_ERR_ARG, "unknown expm method");
+        if (max_order < 1 || max_order > MAX_ORDER) return fail(MMW_ERR_ARG, "max_order must be in [1,16]");
+        if (!(tol > 0)) return fail(MMW_ERR_ARG, "tol must be positive");
+        eng.method = method; eng.max_order = max_order; eng.tol = tol;
+        return MMW_OK;
+    }
+    int set_timing(int enabled) override {
+        timing = enabled != 0;
+        return MMW_OK;
+    }
+
+    int reset(int32_t nit_) override {
+        if (host_only) return fail(MMW_ERR_STATE, "this handle was created with device -1 (host pattern only)");
+        MMW_HIP(hipSetDevice(device));
+        if (nit_ < 1) return fail(MMW_ERR_ARG, "nit must be >= 1");
+        nit = nit_;
+        iter = 0;
+        const size_t nnz = (size_t)H.nnzL(), C = (size_t)H.C();
+        MMW_HIP(hipMemsetAsync(lval.p, 0, nnz * sizeof(T), st));
+        MMW_HIP(hipMemsetAsync(xval.p, 0, nnz * sizeof(T), st));
+        MMW_HIP(hipMemsetAsync(xavg.p, 0, nnz * sizeof(T), st));
+        MMW_HIP(hipMemsetAsync(e_accu.p, 0, C * sizeof(T), st));
+        MMW_HIP(hipMemsetAsync(e_this.p, 0, C * sizeof(T), st));
+        hipLaunchKernelGGL((k_set_identity<T>), dim3(grid_elems(K)), dim3(BLOCK), 0, st, K, d_diag.p, xval.p, xavg.p);
+        const T y0 = (T)(1.0 / (double)C);
+        hipLaunchKernelGGL((k_fill<T>), dim3(grid_elems(C)), dim3(BLOCK), 0, st, C, Y.p, y0);
+        hipLaunchKernelGGL((k_fill<T>), dim3(grid_elems(C)), dim3(BLOCK), 0, st, C, yavg.p, y0);
+        MMW_HIP(hipGetLastError());
+        phase_us.clear();
+        return MMW_OK;
+    }
+
+    int record(int slot) {
+        if (!timing) return MMW_OK;
+        hipEvent_t e;
+        MMW_HIP(hipEventCreate(&e));
+        MMW_HIP(hipEventRecord(e, st));
+        events.push_back(e);
+        (void)slot;
+        return MMW_OK;
+    }
+    int flush_events() {
+        if (events.empty()) return MMW_OK;
+        MMW_HIP(hipStreamSynchronize(st));
+        for (size_t i = 0; i + 3 < events.size(); i += 4) {
+            float a = 0, b = 0, c = 0, t = 0;
+            MMW_HIP(hipEventElapsedTime(&a, events[i], events[i + 1]));
+            MMW_HIP(hipEventElapsedTime(&b, events[i + 1], events[i + 2]));
+            MMW_HIP(hipEventElapsedTime(&c, events[i + 2], events[i + 3]));
+            MMW_HIP(hipEventElapsedTime(&t, events[i], events[i + 3]));
+            phase_us.push_back(a * 1e3); phase_us.push_back(b * 1e3); phase_us.push_back(c * 1e3); phase_us.push_back(t * 1e3);
+        }
+        for (auto e : events) (void)hipEventDestroy(e);
+        events.clear();
+        return MMW_OK;
+    }
+
+    int iterate(int32_t n, const double* randv, uint64_t seed) override {
+        if (host_only) return fail(MMW_ERR_STATE, "this handle was created with device -1 (host pattern only)");
+        MMW_HIP(hipSetDevice(device));
+        if (n < 0) return fail(MMW_ERR_ARG, "n must be >= 0");
+        if (iter + n > nit) return fail(MMW_ERR_STATE, "mmw_iterate: more iterations than announced to mmw_create/mmw_reset");
+        const PatternDev<T> P = pat();
+        const int gr = grid_rows(K);
+        const int C = (int)H.C();
+        const int gc = grid_elems((size_t)C);
+        const int Dpad = eng.lay.Dpad;
+        for (int it = 0; it < n; ++it) {
+            const int acc = (iter + 1 < nit) ? 1 : 0;  // the last X / Y are not averaged (mmw.py:77-78,203)
+            MMW_TRY(record(0));
+            // ---- DUAL
+            hipLaunchKernelGGL((k_dual_rows<T>), dim3(gr), dim3(BLOCK), 0, st, P, xval.p, rsum.p, e_this.p);
+            hipLaunchKernelGGL((k_dual_h<T>), dim3(gr), dim3(BLOCK), 0, st, P, rsum.p, e_this.p, e_accu.p, eta, max_part.p);
+            hipLaunchKernelGGL((k_softmax_a<T>), dim3(gc), dim3(BLOCK), 0, st, P, e_accu.p, Y.p, max_part.p, gr, sum_part.p);
+            hipLaunchKernelGGL((k_softmax_b<T>), dim3(gc), dim3(BLOCK), 0, st, C, Y.p, yavg.p, acc, sum_part.p, gc, scal.p);
+            MMW_TRY(record(1));
+            // ---- LOSS
+            hipLaunchKernelGGL((k_loss<T>), dim3(gr), dim3(BLOCK), 0, st, P, Y.p, scal.p, lval.p, eta, trace_part.p);
+            MMW_TRY(record(2));
+            // ---- EXPM + X on the pattern
+            if (randv) {
+                MMW_HIP(hipMemcpyAsync(stage64.p, randv + (size_t)it * K * D, (size_t)K * D * sizeof(double), hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL((k_import_block<T>), dim3(grid_elems(eng.bs)), dim3(BLOCK), 0, st, K, D, Dpad, stage64.p, eng.start_block());
+                last_was_rng = false;
+            } else {
+                hipLaunchKernelGGL((k_sketch_rng<T>), dim3(gr), dim3(BLOCK), 0, st, K, D, Dpad, seed, (uint32_t)iter, eng.start_block());
+                last_was_rng = true;
+                last_seed = seed;
+            }
+            MMW_HIP(hipGetLastError());
+            MMW_TRY(eng.apply(Xh.p, 0.5, trace_part.p, gr));
+            hipLaunchKernelGGL((k_rownorm2<T>), dim3(gr), dim3(BLOCK), 0, st, K, Dpad, Xh.p, drow.p, tr_part.p);
+            switch (eng.lay.NCH) {
+                case 1: hipLaunchKernelGGL((k_sddmm<T, 1>), dim3(gr), dim3(BLOCK), 0, st, P, Dpad, eng.lay.LPR, eng.lay.G, Xh.p, drow.p, tr_part.p, gr, xval.p, xavg.p, acc); break;
+                case 2: hipLaunchKernelGGL((k_sddmm<T, 2>), dim3(gr), dim3(BLOCK), 0, st, P, Dpad, eng.lay.LPR, eng.lay.G, Xh.p, drow.p, tr_part.p, gr, xval.p, xavg.p, acc); break;
+                case 3: hipLaunchKernelGGL((k_sddmm<T, 3>), dim3(gr), dim3(BLOCK), 0, st, P, Dpad, eng.lay.LPR, eng.lay.G, Xh.p, drow.p, tr_part.p, gr, xval.p, xavg.p, acc); break;
+                default: hipLaunchKernelGGL((k_sddmm<T, 4>), dim3(gr), dim3(BLOCK), 0, st, P, Dpad, eng.lay.LPR, eng.lay.G, Xh.p, drow.p, tr_part.p, gr, xval.p, xavg.p, acc); break;
+            }
+            MMW_HIP(hipGetLastError());
+            MMW_TRY(record(3));
+            ++iter;
+        }
+        return MMW_OK;
+    }
+    int sync() override {
+        if (host_only) return fail(MMW_ERR_STATE, "this handle was created with device -1 (host pattern only)");
+        MMW_HIP(hipSetDevice(device));
+        MMW_HIP(hipStreamSynchronize(st));
+        return flush_events();
+    }
+
+    int export_T(const T* src, size_t n, double* out, int64_t have) {
+        if ((int64_t)n != have) return fail(MMW_ERR_ARG, "mmw_read_f64: wrong length " + std::to_string(have) + ", expected " + std::to_string(n));
+        hipLaunchKernelGGL((k_to_f64<T>), dim3(grid_elems(n)), dim3(BLOCK), 0, st, n, src, out64.p);
+        MMW_HIP(hipGetLastError());
+        MMW_HIP(hipMemcpyAsync(out, out64.p, n * sizeof(double), hipMemcpyDeviceToHost, st));
+        MMW_HIP(hipStreamSynchronize(st));
+        return MMW_OK;
+    }
+    int export_host(const std::vector<double>& v, double* out, int64_t have) {
+        if ((int64_t)v.size() != have) return fail(MMW_ERR_ARG, "mmw_read_f64: wrong length");
+        if (!v.empty()) memcpy(out, v.data(), v.size() * sizeof(double));
+        return MMW_OK;
+    }
+    int export_block(const T* src, double* out, int64_t have) {
+        const size_t n = (size_t)K * D;
+        if ((int64_t)n != have) return fail(MMW_ERR_ARG, "mmw_read_f64: wrong length for a K x D block");
+        hipLaunchKernelGGL((k_export_block<T>), dim3(grid_elems(n)), dim3(BLOCK), 0, st, K, D, eng.lay.Dpad, src, out64.p);
+        MMW_HIP(hipGetLastError());
+        MMW_HIP(hipMemcpyAsync(out, out64.p, n * sizeof(double), hipMemcpyDeviceToHost, st));
+        MMW_HIP(hipStreamSynchronize(st));
+        return MMW_OK;
+    }
+    int read_f64(int which, double* out, int64_t n) override {
+        if (host_only) {
+            switch (which) {
+                case MMW_F_S_SUM: return export_host(H.S_sum, out, n);
+                case MMW_F_NORM_H: return export_host(H.norm_H, out, n);
+                case MMW_F_ST_DATA: return export_host(H.st_data, out, n);
+                default: return fail(MMW_ERR_STATE, "this handle was created with device -1 (host pattern only)");
+            }
+        }
+        MMW_HIP(hipSetDevice(device));
+        MMW_TRY(sync());
+        const size_t nnz = (size_t)H.nnzL(), C = (size_t)H.C();
+        switch (which) {
+            case MMW_F_Y: return export_T(Y.p, C, out, n);
+            case MMW_F_E_ACCU: return export_T(e_accu.p, C, out, n);
+            case MMW_F_E_THIS: return export_T(e_this.p, C, out, n);
+            case MMW_F_LVAL: return export_T(lval.p, nnz, out, n);
+            case MMW_F_XVAL: return export_T(xval.p, nnz, out, n);
+            case MMW_F_XAVG: return export_T(xavg.p, nnz, out, n);
+            case MMW_F_YAVG: return export_T(yavg.p, C, out, n);
+            case MMW_F_XHALF: return export_block(Xh.p, out, n);
+            case MMW_F_SKETCH: {
+                if (!last_was_rng || iter == 0) return fail(MMW_ERR_STATE, "the sketch can be read back only after a device-generated iteration");
+                hipLaunchKernelGGL((k_sketch_rng<T>), dim3(grid_rows(K)), dim3(BLOCK), 0, st, K, D, eng.lay.Dpad, last_seed, (uint32_t)(iter - 1), eng.Tm.p);
+                return export_block(eng.Tm.p, out, n);
+            }
+            case MMW_F_S_SUM: return export_host(H.S_sum, out, n);
+            case MMW_F_NORM_H: return export_host(H.norm_H, out, n);
+            case MMW_F_ST_DATA: return export_host(H.st_data, out, n);
+            case MMW_F_PHASE_US: return export_host(phase_us, out, n);
+            case MMW_F_EXPM_INFO: {
+                if (n != 4) return fail(MMW_ERR_ARG, "expm info has 4 entries");
+                out[0] = eng.last.rho; out[1] = eng.last.m; out[2] = eng.last.nsub; out[3] = eng.last.mu;
+                return MMW_OK;
+            }
+            case MMW_F_FACTOR: return extras.read_factor(out, n);
+            default: return fail(MMW_ERR_ARG, "mmw_read_f64: unknown field");
+        }
+    }
+    int export_i32(const std::vector<int32_t>& v, int32_t* out, int64_t have) {
+        if ((int64_t)v.size() != have) return fail(MMW_ERR_ARG, "mmw_read_i32: wrong length");
+        if (!v.empty()) memcpy(out, v.data(), v.size() * sizeof(int32_t));
+        return MMW_OK;
+    }
+    int read_i32(int which, int32_t* out, int64_t n) override {
+        switch (which) {
+            case MMW_I_L_INDPTR: return export_i32(H.l_indptr, out, n);
+            case MMW_I_L_INDICES: return export_i32(H.l_indices, out, n);
+            case MMW_I_ST_INDPTR: return export_i32(H.st_indptr, out, n);
+            case MMW_I_ST_INDICES: return export_i32(H.st_indices, out, n);
+            case MMW_I_GAIN_X: return export_i32(H.gain_x, out, n);
+            case MMW_I_GAIN_Y: return export_i32(H.gain_y, out, n);
+            case MMW_I_ASSO_X: return export_i32(H.asso_x, out, n);
+            case MMW_I_ASSO_Y: return export_i32(H.asso_y, out, n);
+            case MMW_I_DIAG_POS: return export_i32(H.diag_pos, out, n);
+            case MMW_I_ASSO_POS: return export_i32(H.asso_pos, out, n);
+            default: return fail(MMW_ERR_ARG, "mmw_read_i32: unknown field");
+        }
+    }
+    int gap(double out[3]) override {
+        if (host_only) return fail(MMW_ERR_STATE, "host-only handle");
+        return extras.gap(out);
+    }
+    int factor(int32_t rank, double* out, uint64_t seed) override {
+        if (host_only) return fail(MMW_ERR_STATE, "host-only handle");
+        return extras.factor(rank, out, seed);
+    }
+    int round(int32_t Zr, int32_t Dp, const double* gX, int32_t nbatch, const double* randv, int32_t* z_out, int32_t* rem_out) override {
+        if (host_only) return fail(MMW_ERR_STATE, "host-only handle");
+        return extras.round(Zr, Dp, gX, nbatch, randv, z_out, rem_out);
+    }
+};
+
+template <typename T>
+int expm_apply_impl(int device, int method, int max_order, double tol, int32_t K, int32_t D, const int32_t* indptr,
+                    const int32_t* indices, const double* data, const double* B, double* out, double info[4], int32_t reps,
+                    double* kernel_us) {
+    MMW_HIP(hipSetDevice(device));
+    hipStream_t st;
+    MMW_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    struct Guard {
+        hipStream_t s;
+        ~Guard() { (void)hipStreamDestroy(s); }
+    } guard{st};
+    const int64_t nnz = indptr[K];
+    std::vector<int32_t> ip(indptr, indptr + K + 1), ci(indices, indices + nnz);
+    std::vector<double> vv(data, data + nnz);
+    DevBuf<int> d_ip, d_ci;
+    DevBuf<T> d_v, d_out;
+    DevBuf<double> d_b64, d_o64;
+    MMW_TRY(d_ip.upload(ip, st));
+    MMW_TRY(d_ci.upload(ci, st));
+    MMW_TRY(d_v.upload_cast(vv, st));
+    ExpmEngine<T> eng;
+    MMW_TRY(eng.init(st, K, D, d_ip.p, d_ci.p, d_v.p));
+    eng.method = method; eng.max_order = max_order; eng.tol = tol;
+    MMW_TRY(d_out.alloc(eng.bs));
+    MMW_TRY(d_b64.alloc((size_t)K * D));
+    MMW_TRY(d_o64.alloc((size_t)K * D));
+    MMW_HIP(hipMemcpyAsync(d_b64.p, B, (size_t)K * D * sizeof(double), hipMemcpyHostToDevice, st));
+    hipEvent_t e0, e1;
+    MMW_HIP(hipEventCreate(&e0));
+    MMW_HIP(hipEventCreate(&e1));
+    double us = 0.0;
+    if (reps < 1) reps = 1;
+    for (int r = 0; r < reps; ++r) {
+        hipLaunchKernelGGL((k_import_block<T>), dim3(grid_elems(eng.bs)), dim3(BLOCK), 0, st, K, D, eng.lay.Dpad, d_b64.p, eng.start_block());
+        MMW_HIP(hipEventRecord(e0, st));
+        int rc = eng.apply(d_out.p, 1.0);
+        if (rc != MMW_OK) return rc;
+        MMW_HIP(hipEventRecord(e1, st));
+        MMW_HIP(hipStreamSynchronize(st));
+        float ms = 0;
+        MMW_HIP(hipEventElapsedTime(&ms, e0, e1));
+        us += ms * 1e3;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    hipLaunchKernelGGL((k_export_block<T>), dim3(grid_elems((size_t)K * D)), dim3(BLOCK), 0, st, K, D, eng.lay.Dpad, d_out.p, d_o64.p);
+    MMW_HIP(hipGetLastError());
+    MMW_HIP(hipMemcpyAsync(out, d_o64.p, (size_t)K * D * sizeof(double), hipMemcpyDeviceToHost, st));
+    MMW_HIP(hipStreamSynchronize(st));
+    if (info) {
+        info[0] = eng.last.rho; info[1] = eng.last.m; info[2] = eng.last.nsub; info[3] = eng.last.mu;
+    }
+    if (kernel_us) *kernel_us = us / reps;
+    return MMW_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mmw_last_error(void) { return last_error_ref().c_str(); }
+int mmw_version(void) { return 100; }
+int mmw_device_count(int* n) {
+    if (!n) return fail(MMW_ERR_ARG, "null pointer");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *n = 0;
+        return fail(MMW_ERR_HIP, std::string("hipGetDeviceCount failed: ") + hipGetErrorString(e));
+    }
+    *n = c;
+    return MMW_OK;
+}
+
+int mmw_create(mmw_solver** out, int device, int dtype, int32_t K, int32_t Z, int32_t rank_radio, double eta, int32_t nit,
+               const int32_t* S_indptr, const int32_t* S_indices, const double* S_data, const int32_t* Q_indptr,
+               const int32_t* Q_indices, const double* Q_data, const double* h_max) {
+    if (!out || !S_indptr || !S_indices || !S_data || !Q_indptr || !Q_indices || !Q_data || !h_max)
+        return fail(MMW_ERR_ARG, "mmw_create: null pointer");
+    *out = nullptr;
+    if (rank_radio < 1) return fail(MMW_ERR_ARG, "rank_radio must be >= 1");
+    if (nit < 1) return fail(MMW_ERR_ARG, "nit must be >= 1");
+    const bool host_only = device == -1;
+    if (!host_only) {
+        int ndev = 0;
+        MMW_TRY(mmw_device_count(&ndev));
+        if (device < 0 || device >= ndev) return fail(MMW_ERR_HIP, "mmw_create: no such HIP device " + std::to_string(device) + " (" + std::to_string(ndev) + " visible)");
+    }
+    int rc;
+    if (dtype == MMW_F32) {
+        auto s = std::make_unique<Solver<float>>();
+        s->host_only = host_only;
+        rc = s->init(device, K, Z, rank_radio, eta, nit, S_indptr, S_indices, S_data, Q_indptr, Q_indices, Q_data, h_max);
+        if (rc == MMW_OK) *out = s.release();
+    } else if (dtype == MMW_F64) {
+        auto s = std::make_unique<Solver<double>>();
+        s->host_only = host_only;
+        rc = s->init(device, K, Z, rank_radio, eta, nit, S_indptr, S_indices, S_data, Q_indptr, Q_indices, Q_data, h_max);
+        if (rc == MMW_OK) *out = s.release();
+    } else {
+        rc = fail(MMW_ERR_ARG, "dtype must be MMW_F32 or MMW_F64");
+    }
+    return rc;
+}
+int mmw_destroy(mmw_solver* s) {
+    delete s;
+    return MMW_OK;
+}
+#define MMW_NEED(s) \
+    if (!(s)) return fail(MMW_ERR_ARG, "null solver handle")
+int mmw_sizes(mmw_solver* s, int64_t out[10]) { MMW_NEED(s); return s->sizes(out); }
+int mmw_set_expm(mmw_solver* s, int method, int max_order, double tol) { MMW_NEED(s); return s->set_expm(method, max_order, tol); }
+int mmw_set_timing(mmw_solver* s, int enabled) { MMW_NEED(s); return s->set_timing(enabled); }
+int mmw_reset(mmw_solver* s, int32_t nit) { MMW_NEED(s); return s->reset(nit); }
+int mmw_iterate(mmw_solver* s, int32_t n, const double* randv, uint64_t seed) { MMW_NEED(s); return s->iterate(n, randv, seed); }
+int mmw_sync(mmw_solver* s) { MMW_NEED(s); return s->sync(); }
+int mmw_read_f64(mmw_solver* s, int which, double* out, int64_t n) { MMW_NEED(s); if (!out && n) return fail(MMW_ERR_ARG, "null output"); return s->read_f64(which, out, n); }
+int mmw_read_i32(mmw_solver* s, int which, int32_t* out, int64_t n) { MMW_NEED(s); if (!out && n) return fail(MMW_ERR_ARG, "null output"); return s->read_i32(which, out, n); }
+int mmw_gap(mmw_solver* s, double out[3]) { MMW_NEED(s); return s->gap(out); }
+int mmw_factor(mmw_solver* s, int32_t rank, double* out, uint64_t seed) { MMW_NEED(s); return s->factor(rank, out, seed); }
+int mmw_round(mmw_solver* s, int32_t Zr, int32_t Dp, const double* gX, int32_t nbatch, const double* randv, int32_t* z_out, int32_t* rem_out) {
+    MMW_NEED(s);
+    return s->round(Zr, Dp, gX, nbatch, randv, z_out, rem_out);
+}
+
+int mmw_expm_apply(int device, int dtype, int method, int max_order, double tol, int32_t K, int32_t D, const int32_t* indptr,
+                   const int32_t* indices, const double* data, const double* B, double* out, double info[4], int32_t reps,
+                   double* kernel_us) {
+    if (!indptr || !indices || !data || !B || !out) return fail(MMW_ERR_ARG, "mmw_expm_apply: null pointer");
+    if (K < 1 || D < 1) return fail(MMW_ERR_ARG, "mmw_expm_apply: K and D must be positive");
+    if (max_order < 1 || max_order > MAX_ORDER) return fail(MMW_ERR_ARG, "max_order must be in [1,16]");
+    if (method != MMW_EXPM_LANCZOS && method != MMW_EXPM_TAYLOR) return fail(MMW_ERR_ARG, "unknown expm method");
+    int ndev = 0;
+    MMW_TRY(mmw_device_count(&ndev));
+    if (device < 0 || device >= ndev) return fail(MMW_ERR_HIP, "mmw_expm_apply: no such HIP device");
+    if (dtype == MMW_F32) return expm_apply_impl<float>(device, method, max_order, tol, K, D, indptr, indices, data, B, out, info, reps, kernel_us);
+    if (dtype == MMW_F64) return expm_apply_impl<double>(device, method, max_order, tol, K, D, indptr, indices, data, B, out, info, reps, kernel_us);
+    return fail(MMW_ERR_ARG, "dtype must be MMW_F32 or MMW_F64");
+}
+
+}  // extern "C"

@@ -1,0 +1,162 @@
+"""GPU parity of the device-resident MMW loop (through the C-ABI) against the golden vectors of the
+reference and against the CPU oracle.
+
+Tolerances: the north star asks <= 1e-5 relative Frobenius on exp(L/2)R; with the Krylov tolerance set
+tight the fp64 path is held to 1e-9 on every per-iteration quantity, the fp32 path to 1e-4 / 1e-5.
+"""
+import numpy as np
+import pytest
+
+from conftest import csr_from, load_golden, relerr, state_from
+from oracle import mmw_oracle as orc
+from sig_sdp_mmw_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def pattern_csr(s, vals):
+    import scipy.sparse
+    return scipy.sparse.csr_matrix((vals, s.read_i32(_lib.I_L_INDICES), s.read_i32(_lib.I_L_INDPTR)), shape=(s.K, s.K))
+
+
+@pytest.mark.parametrize("method", [_lib.EXPM_LANCZOS, _lib.EXPM_TAYLOR])
+def test_trajectory_matches_reference_fp64(run_case, method):
+    name, g = run_case
+    state = state_from(g)
+    Z, nit, eta = int(g["Z"]), int(g["nit"]), float(g["eta"])
+    s = _lib.Solver(Z, state, nit, eta, dtype=_lib.F64)
+    s.set_expm(method, 16, 1e-13)
+    diag = s.read_i32(_lib.I_DIAG_POS)
+    for i in range(nit):
+        s.iterate(1, g["randv"][i])
+        assert relerr(s.read(_lib.F_E_THIS), g["e_this"][i]) < 1e-9, (name, i)
+        assert relerr(s.read(_lib.F_E_ACCU), g["e_accu"][i]) < 1e-9
+        assert relerr(s.read(_lib.F_Y), g["Y"][i]) < 1e-9
+        L = pattern_csr(s, s.read(_lib.F_LVAL))
+        Lref = csr_from(g, "Laccu%d" % i)
+        assert abs(L - Lref).max() < 1e-10 * max(1e-3, abs(Lref).max())
+        assert relerr(s.read(_lib.F_XHALF), g["X_half_it"][i]) < 1e-9
+        xv = s.read(_lib.F_XVAL)
+        assert relerr(xv[diag], g["X_mdiag"][i]) < 1e-9
+        xo = xv.copy()
+        xo[diag] = 0
+        assert abs(pattern_csr(s, xo) - csr_from(g, "Xoffdi%d" % i)).max() < 1e-9
+    xavg = pattern_csr(s, s.read(_lib.F_XAVG) / nit)
+    assert abs(xavg - csr_from(g, "Xavgd")).max() < 1e-9
+    info = s.read(_lib.F_EXPM_INFO)
+    assert 1 <= info[1] <= 16 and info[2] == 1
+    s.close()
+
+
+def test_trajectory_fp32_within_tolerance(run_case):
+    name, g = run_case
+    state = state_from(g)
+    Z, nit, eta = int(g["Z"]), int(g["nit"]), float(g["eta"])
+    s = _lib.Solver(Z, state, nit, eta, dtype=_lib.F32)
+    s.set_expm(_lib.EXPM_LANCZOS, 12, 1e-7)
+    for i in range(nit):
+        s.iterate(1, g["randv"][i])
+        assert relerr(s.read(_lib.F_XHALF), g["X_half_it"][i]) < 1e-5, (name, i)  # north-star bar
+        assert relerr(s.read(_lib.F_Y), g["Y"][i]) < 1e-4
+    s.close()
+
+
+def test_batched_iterate_equals_stepwise(run_case):
+    name, g = run_case
+    state = state_from(g)
+    Z, nit, eta = int(g["Z"]), int(g["nit"]), float(g["eta"])
+    a = _lib.Solver(Z, state, nit, eta)
+    b = _lib.Solver(Z, state, nit, eta)
+    a.iterate(nit, g["randv"][:nit])
+    for i in range(nit):
+        b.iterate(1, g["randv"][i])
+    for f in (_lib.F_Y, _lib.F_LVAL, _lib.F_XVAL, _lib.F_XAVG, _lib.F_YAVG):
+        assert np.array_equal(a.read(f), b.read(f))  # bitwise reproducible: no atomics anywhere
+    with pytest.raises(_lib.MMWError):
+        a.iterate(1, g["randv"][0])  # more than the announced nit
+    a.reset(nit)
+    a.iterate(nit, g["randv"][:nit])
+    assert np.array_equal(a.read(_lib.F_XVAL), b.read(_lib.F_XVAL))
+    a.close()
+    b.close()
+
+
+def test_default_tolerance_meets_north_star_bar(run_case):
+    """Default Krylov tolerance (order chosen on the device from the one-norm bound)."""
+    name, g = run_case
+    state = state_from(g)
+    Z, nit, eta = int(g["Z"]), int(g["nit"]), float(g["eta"])
+    for dtype, bar in ((_lib.F64, 1e-7), (_lib.F32, 1e-5)):
+        s = _lib.Solver(Z, state, nit, eta, dtype=dtype)
+        for i in range(nit):
+            s.iterate(1, g["randv"][i])
+            assert relerr(s.read(_lib.F_XHALF), g["X_half_it"][i]) < bar
+        s.close()
+
+
+@pytest.mark.parametrize("dtype,tol,bar", [(_lib.F64, 1e-12, 1e-10), (_lib.F64, 1e-6, 1e-5), (_lib.F32, 1e-6, 1e-5)])
+@pytest.mark.parametrize("method", [_lib.EXPM_LANCZOS, _lib.EXPM_TAYLOR])
+def test_expm_seam_all_norms(dtype, tol, bar, method):
+    """mmw.expm_half_randsk seam at one-norms 0.004 ... 12.6 (substeps kick in at the top)."""
+    g = load_golden("expm_seam")
+    L = csr_from(g, "L")
+    for i, sc in enumerate(g["scales"]):
+        Ls = L.copy()
+        Ls.data = Ls.data * sc
+        out, info = _lib.expm_apply(Ls, g["randv%d" % i], dtype=dtype, method=method, max_order=16, tol=tol)
+        assert relerr(out, g["X%d" % i]) < bar, (i, info)
+        assert info["one_norm"] >= float(g["onenorm%d" % i]) * (1 - 1e-6)
+        assert info["one_norm"] <= float(g["onenorm%d" % i]) * 1.0001 + 1e-12
+    assert info["substeps"] > 1
+
+
+def test_expm_zero_matrix_and_odd_widths():
+    import scipy.sparse
+    rng = np.random.default_rng(0)
+    K = 97
+    for D in (1, 3, 5, 31, 40, 70, 140, 300):
+        B = rng.standard_normal((K, D))
+        Z0 = scipy.sparse.csr_matrix((K, K))
+        out, info = _lib.expm_apply(Z0, B)
+        assert relerr(out, B) < 1e-14
+        A = scipy.sparse.random(K, K, 0.1, random_state=1)
+        A = (A + A.T) * 0.3
+        ref = orc.expm_half(A.tocsr(), B)
+        for dt, bar in ((_lib.F64, 1e-9), (_lib.F32, 2e-6)):
+            out, info = _lib.expm_apply(A.tocsr(), B, dtype=dt, tol=1e-11 if dt == _lib.F64 else 1e-7, max_order=16)
+            assert relerr(out, ref) < bar, (D, dt, info)
+
+
+def test_device_sketch_rows_are_unit_gaussian_directions():
+    from sig_sdp_mmw_amd.graphs import er_contention_graph
+    state = er_contention_graph(500, 0.03, 2)
+    s = _lib.Solver(20, state, 2, 0.05)
+    s.iterate(1, None, seed=123)
+    R = s.read(_lib.F_SKETCH)
+    assert R.shape == (500, 40)
+    np.testing.assert_allclose(np.linalg.norm(R, axis=1), 1.0, rtol=1e-12)
+    # isotropy: mean ~ 0, second moment ~ 1/D, no duplicated rows, different per iteration/seed
+    assert abs(R.mean()) < 5e-3
+    assert abs((R ** 2).mean() - 1 / 40) < 1e-3
+    assert len({r.tobytes() for r in R}) == 500
+    s.iterate(1, None, seed=123)
+    assert not np.array_equal(R, s.read(_lib.F_SKETCH))
+    t = _lib.Solver(20, state, 2, 0.05)
+    t.iterate(1, None, seed=123)
+    assert np.array_equal(R, t.read(_lib.F_SKETCH))  # counter-based: same seed, same iteration -> same draw
+    # and the iterate it produced is the oracle's on that sketch
+    o = orc.MMWOracle(nit=1, eta=0.05)
+    o.run(20, state, lambda i, K, D: R, keep_trace=True, factor=False)
+    assert relerr(t.read(_lib.F_XHALF), o.trace["X_half"][0]) < 1e-7
+    s.close()
+    t.close()
+
+
+def test_phase_timers_are_filled():
+    from sig_sdp_mmw_amd.graphs import er_contention_graph
+    s = _lib.Solver(8, er_contention_graph(300, 0.05, 3), 5, 0.05, dtype=_lib.F32)
+    s.set_timing(True)
+    s.iterate(5, None, seed=1)
+    t = s.read(_lib.F_PHASE_US).reshape(5, 4)
+    assert np.all(t > 0) and np.all(t[:, 3] >= t[:, :3].max(axis=1))
+    s.close()
