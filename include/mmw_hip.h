@@ -57,7 +57,9 @@ enum mmw_field {
     MMW_F_ST_DATA = 11,   /* [nnzST]  values of S_T' in CSR order (mmw.py:28-33)        */
     MMW_F_PHASE_US = 12,  /* [4*iters] per-iteration device us: dual, loss, expm, total (mmw.py:141,169,196,199) */
     MMW_F_EXPM_INFO = 13, /* [4]      last plan: one-norm bound, Krylov order m, substeps, shift mu */
-    MMW_F_FACTOR = 14     /* [K*rank] last factor of the averaged X (mmw.py:213-216)    */
+    MMW_F_FACTOR = 14,    /* [K*rank] last factor of the averaged X (mmw.py:213-216)    */
+    MMW_F_KERNEL_US = 15  /* [2*9]    per kernel class {total device us, launches} since mmw_set_profile(1):
+                             spmm, sddmm, dual, loss, krylov vector ops, sketch, projection, greedy, factor */
 };
 enum mmw_ifield {
     MMW_I_L_INDPTR = 0,   /* [K+1]   */
@@ -99,6 +101,9 @@ int mmw_sizes(mmw_solver* s, int64_t out[10]);
 int mmw_set_expm(mmw_solver* s, int method, int max_order, double tol);
 /* 1: record HIP events around every phase (fills MMW_F_PHASE_US); 0: none, iterations run back to back. */
 int mmw_set_timing(mmw_solver* s, int enabled);
+
+/* 1: bracket every kernel class with HIP events on the solver's stream (fills MMW_F_KERNEL_US); clears the sums */
+int mmw_set_profile(mmw_solver* s, int enabled);
 
 /* back to the initial point of mmw.py:62-73 for a fresh run of `nit` iterations on the same (state, Z) */
 int mmw_reset(mmw_solver* s, int32_t nit);

@@ -209,8 +209,8 @@ class MMWOracle:
         self.expm = expm
         self.trace = None
 
-    def run(self, Z, state, sketch, keep_trace=False, factor=True, v0=None):
-        p = Pattern(Z, state)
+    def run(self, Z, state, sketch, keep_trace=False, factor=True, v0=None, pattern=None):
+        p = Pattern(Z, state) if pattern is None else pattern
         K, C, eta = p.K, p.C, self.eta
         D = Z * self.rank_radio
         Y = np.ones(C) / C

@@ -16,11 +16,12 @@ EXPM_LANCZOS, EXPM_TAYLOR = 0, 1
 
 # enum mmw_field / mmw_ifield
 F_Y, F_E_ACCU, F_E_THIS, F_LVAL, F_XVAL, F_XAVG, F_YAVG, F_XHALF, F_SKETCH = range(9)
-F_S_SUM, F_NORM_H, F_ST_DATA, F_PHASE_US, F_EXPM_INFO, F_FACTOR = range(9, 15)
+F_S_SUM, F_NORM_H, F_ST_DATA, F_PHASE_US, F_EXPM_INFO, F_FACTOR, F_KERNEL_US = range(9, 16)
+KERNEL_CLASSES = ["spmm", "sddmm", "dual", "loss", "krylov_vec", "sketch", "project", "greedy", "factor"]
 I_L_INDPTR, I_L_INDICES, I_ST_INDPTR, I_ST_INDICES, I_GAIN_X, I_GAIN_Y, I_ASSO_X, I_ASSO_Y, I_DIAG_POS, I_ASSO_POS = range(10)
 
 EXPORTS = ["mmw_last_error", "mmw_version", "mmw_device_count", "mmw_create", "mmw_destroy", "mmw_sizes", "mmw_set_expm",
-           "mmw_set_timing", "mmw_reset", "mmw_iterate", "mmw_sync", "mmw_read_f64", "mmw_read_i32", "mmw_gap",
+           "mmw_set_timing", "mmw_set_profile", "mmw_reset", "mmw_iterate", "mmw_sync", "mmw_read_f64", "mmw_read_i32", "mmw_gap",
            "mmw_factor", "mmw_expm_apply", "mmw_round"]
 
 
@@ -52,6 +53,7 @@ def lib():
     L.mmw_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     L.mmw_set_expm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double]
     L.mmw_set_timing.argtypes = [C.c_void_p, C.c_int]
+    L.mmw_set_profile.argtypes = [C.c_void_p, C.c_int]
     L.mmw_reset.argtypes = [C.c_void_p, C.c_int32]
     L.mmw_iterate.argtypes = [C.c_void_p, C.c_int32, p_f64, C.c_uint64]
     L.mmw_sync.argtypes = [C.c_void_p]
@@ -150,6 +152,15 @@ class Solver:
     def set_timing(self, on):
         check(lib().mmw_set_timing(self._h, 1 if on else 0))
         self._timing = bool(on)
+
+    def set_profile(self, on):
+        check(lib().mmw_set_profile(self._h, 1 if on else 0))
+
+    def kernel_times(self):
+        """{class: (total device us, launches)} since set_profile(True)."""
+        self.sync()
+        v = self.read(F_KERNEL_US, 2 * len(KERNEL_CLASSES))
+        return {k: (float(v[2 * i]), int(v[2 * i + 1])) for i, k in enumerate(KERNEL_CLASSES)}
 
     def reset(self, nit):
         check(lib().mmw_reset(self._h, int(nit)))

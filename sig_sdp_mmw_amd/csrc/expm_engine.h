@@ -48,7 +48,9 @@ template <typename T> struct ExpmEngine {
     ExpmPlan* plan_h = nullptr;  // pinned
     ExpmPlan last{};
     size_t bs = 0;      // elements per block
-    double spmm_ms_accum = 0.0;
+    KernelTimers* kt = nullptr;  // optional
+    int kbegin(int slot) { return kt ? kt->begin(slot) : MMW_OK; }
+    int kend() { return kt ? kt->end() : MMW_OK; }
 
     ~ExpmEngine() {
         if (plan_h) (void)hipHostFree(plan_h);
@@ -89,12 +91,14 @@ template <typename T> struct ExpmEngine {
 
     template <int MODE> int launch_spmm(const T* in, T* out, T* F, double ascale, double shift, double inv_k) {
         const size_t sh = MODE == SPMM_LANCZOS ? (size_t)WAVES_PER_BLOCK * lay.Dpad * sizeof(double) : 0;
+        MMW_TRY(kbegin(KT_SPMM));
         switch (lay.NCH) {
             case 1: hipLaunchKernelGGL((k_spmm<T, 1, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, ascale, shift, inv_k, partial.p); break;
             case 2: hipLaunchKernelGGL((k_spmm<T, 2, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, ascale, shift, inv_k, partial.p); break;
             case 3: hipLaunchKernelGGL((k_spmm<T, 3, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, ascale, shift, inv_k, partial.p); break;
             default: hipLaunchKernelGGL((k_spmm<T, 4, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, ascale, shift, inv_k, partial.p); break;
         }
+        MMW_TRY(kend());
         MMW_HIP(hipGetLastError());
         return MMW_OK;
     }

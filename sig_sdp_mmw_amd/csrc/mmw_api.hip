@@ -16,6 +16,7 @@ struct mmw_solver {
     virtual int sizes(int64_t out[10]) = 0;
     virtual int set_expm(int method, int max_order, double tol) = 0;
     virtual int set_timing(int enabled) = 0;
+    virtual int set_profile(int enabled) = 0;
     virtual int reset(int32_t nit) = 0;
     virtual int iterate(int32_t n, const double* randv, uint64_t seed) = 0;
     virtual int sync() = 0;
@@ -45,6 +46,7 @@ template <typename T> struct Solver final : mmw_solver {
     DevBuf<double> max_part, sum_part, scal, trace_part, tr_part, stage64, out64;
     ExpmEngine<T> eng;
     Extras<T> extras;
+    KernelTimers kt;
     std::vector<hipEvent_t> events;  // 4 per timed iteration
     std::vector<double> phase_us;
     uint64_t last_seed = 0;
@@ -101,6 +103,8 @@ template <typename T> struct Solver final : mmw_solver {
         MMW_TRY(max_part.alloc(MAX_PART)); MMW_TRY(sum_part.alloc(4 * 2048)); MMW_TRY(scal.alloc(4));
         MMW_TRY(trace_part.alloc(MAX_PART)); MMW_TRY(tr_part.alloc(MAX_PART));
         MMW_TRY(eng.init(st, K, D, d_indptr.p, d_col.p, lval.p));
+        kt.st = st;
+        eng.kt = &kt;
         eng.max_order = 12;
         eng.tol = sizeof(T) == 4 ? 1e-6 : 1e-9;
         MMW_TRY(Xh.alloc(eng.bs));
@@ -126,6 +130,13 @@ template <typename T> struct Solver final : mmw_solver {
     }
     int set_timing(int enabled) override {
         timing = enabled != 0;
+        return MMW_OK;
+    }
+    int set_profile(int enabled) override {
+        if (host_only) return fail(MMW_ERR_STATE, "host-only handle");
+        MMW_TRY(sync());
+        kt.on = enabled != 0;
+        kt.clear();
         return MMW_OK;
     }
 
@@ -189,15 +200,20 @@ template <typename T> struct Solver final : mmw_solver {
             const int acc = (iter + 1 < nit) ? 1 : 0;  // the last X / Y are not averaged (mmw.py:77-78,203)
             MMW_TRY(record(0));
             // ---- DUAL
+            MMW_TRY(kt.begin(KT_DUAL));
             hipLaunchKernelGGL((k_dual_rows<T>), dim3(gr), dim3(BLOCK), 0, st, P, xval.p, rsum.p, e_this.p);
             hipLaunchKernelGGL((k_dual_h<T>), dim3(gr), dim3(BLOCK), 0, st, P, rsum.p, e_this.p, e_accu.p, eta, max_part.p);
             hipLaunchKernelGGL((k_softmax_a<T>), dim3(gc), dim3(BLOCK), 0, st, P, e_accu.p, Y.p, max_part.p, gr, sum_part.p);
             hipLaunchKernelGGL((k_softmax_b<T>), dim3(gc), dim3(BLOCK), 0, st, C, Y.p, yavg.p, acc, sum_part.p, gc, scal.p);
+            MMW_TRY(kt.end());
             MMW_TRY(record(1));
             // ---- LOSS
+            MMW_TRY(kt.begin(KT_LOSS));
             hipLaunchKernelGGL((k_loss<T>), dim3(gr), dim3(BLOCK), 0, st, P, Y.p, scal.p, lval.p, eta, trace_part.p);
+            MMW_TRY(kt.end());
             MMW_TRY(record(2));
             // ---- EXPM + X on the pattern
+            MMW_TRY(kt.begin(KT_SKETCH));
             if (randv) {
                 MMW_HIP(hipMemcpyAsync(stage64.p, randv + (size_t)it * K * D, (size_t)K * D * sizeof(double), hipMemcpyHostToDevice, st));
                 hipLaunchKernelGGL((k_import_block<T>), dim3(grid_elems(eng.bs)), dim3(BLOCK), 0, st, K, D, Dpad, stage64.p, eng.start_block());
@@ -207,8 +223,10 @@ template <typename T> struct Solver final : mmw_solver {
                 last_was_rng = true;
                 last_seed = seed;
             }
+            MMW_TRY(kt.end());
             MMW_HIP(hipGetLastError());
             MMW_TRY(eng.apply(Xh.p, 0.5, trace_part.p, gr));
+            MMW_TRY(kt.begin(KT_SDDMM));
             hipLaunchKernelGGL((k_rownorm2<T>), dim3(gr), dim3(BLOCK), 0, st, K, Dpad, Xh.p, drow.p, tr_part.p);
             switch (eng.lay.NCH) {
                 case 1: hipLaunchKernelGGL((k_sddmm<T, 1>), dim3(gr), dim3(BLOCK), 0, st, P, Dpad, eng.lay.LPR, eng.lay.G, Xh.p, drow.p, tr_part.p, gr, xval.p, xavg.p, acc); break;
@@ -216,6 +234,7 @@ template <typename T> struct Solver final : mmw_solver {
                 case 3: hipLaunchKernelGGL((k_sddmm<T, 3>), dim3(gr), dim3(BLOCK), 0, st, P, Dpad, eng.lay.LPR, eng.lay.G, Xh.p, drow.p, tr_part.p, gr, xval.p, xavg.p, acc); break;
                 default: hipLaunchKernelGGL((k_sddmm<T, 4>), dim3(gr), dim3(BLOCK), 0, st, P, Dpad, eng.lay.LPR, eng.lay.G, Xh.p, drow.p, tr_part.p, gr, xval.p, xavg.p, acc); break;
             }
+            MMW_TRY(kt.end());
             MMW_HIP(hipGetLastError());
             MMW_TRY(record(3));
             ++iter;
@@ -226,6 +245,7 @@ template <typename T> struct Solver final : mmw_solver {
         if (host_only) return fail(MMW_ERR_STATE, "this handle was created with device -1 (host pattern only)");
         MMW_HIP(hipSetDevice(device));
         MMW_HIP(hipStreamSynchronize(st));
+        MMW_TRY(kt.flush());
         return flush_events();
     }
 
@@ -287,6 +307,11 @@ template <typename T> struct Solver final : mmw_solver {
                 return MMW_OK;
             }
             case MMW_F_FACTOR: return extras.read_factor(out, n);
+            case MMW_F_KERNEL_US: {
+                if (n != 2 * KT_NSLOT) return fail(MMW_ERR_ARG, "kernel timers have 2*9 entries");
+                for (int i = 0; i < KT_NSLOT; ++i) { out[2 * i] = kt.total_us[i]; out[2 * i + 1] = kt.count[i]; }
+                return MMW_OK;
+            }
             default: return fail(MMW_ERR_ARG, "mmw_read_f64: unknown field");
         }
     }
@@ -437,6 +462,7 @@ int mmw_destroy(mmw_solver* s) {
 int mmw_sizes(mmw_solver* s, int64_t out[10]) { MMW_NEED(s); return s->sizes(out); }
 int mmw_set_expm(mmw_solver* s, int method, int max_order, double tol) { MMW_NEED(s); return s->set_expm(method, max_order, tol); }
 int mmw_set_timing(mmw_solver* s, int enabled) { MMW_NEED(s); return s->set_timing(enabled); }
+int mmw_set_profile(mmw_solver* s, int enabled) { MMW_NEED(s); return s->set_profile(enabled); }
 int mmw_reset(mmw_solver* s, int32_t nit) { MMW_NEED(s); return s->reset(nit); }
 int mmw_iterate(mmw_solver* s, int32_t n, const double* randv, uint64_t seed) { MMW_NEED(s); return s->iterate(n, randv, seed); }
 int mmw_sync(mmw_solver* s) { MMW_NEED(s); return s->sync(); }

@@ -74,6 +74,54 @@ template <typename T> struct DevBuf {
     }
 };
 
+// Optional per-kernel-class device timers (HIP events on the solver's own stream).  Off by default:
+// when off, begin/end cost nothing and no event is recorded.
+enum { KT_SPMM = 0, KT_SDDMM = 1, KT_DUAL = 2, KT_LOSS = 3, KT_KRYLOV_VEC = 4, KT_SKETCH = 5, KT_PROJECT = 6, KT_GREEDY = 7,
+       KT_FACTOR = 8, KT_NSLOT = 9 };
+struct KernelTimers {
+    bool on = false;
+    hipStream_t st = nullptr;
+    struct Rec { int slot; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    double total_us[KT_NSLOT] = {0};
+    double count[KT_NSLOT] = {0};
+    int cur = -1;
+    ~KernelTimers() {
+        for (auto& r : recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        for (auto e : pool) (void)hipEventDestroy(e);
+    }
+    int get(hipEvent_t* e) {
+        if (!pool.empty()) { *e = pool.back(); pool.pop_back(); return MMW_OK; }
+        MMW_HIP(hipEventCreate(e));
+        return MMW_OK;
+    }
+    int begin(int slot) {
+        if (!on) return MMW_OK;
+        Rec r; r.slot = slot;
+        MMW_TRY(get(&r.a)); MMW_TRY(get(&r.b));
+        MMW_HIP(hipEventRecord(r.a, st));
+        recs.push_back(r);
+        return MMW_OK;
+    }
+    int end() {
+        if (!on || recs.empty()) return MMW_OK;
+        MMW_HIP(hipEventRecord(recs.back().b, st));
+        return MMW_OK;
+    }
+    int flush() {  // call after the stream has been synchronised
+        for (auto& r : recs) {
+            float ms = 0;
+            MMW_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+            total_us[r.slot] += ms * 1e3; count[r.slot] += 1;
+            pool.push_back(r.a); pool.push_back(r.b);
+        }
+        recs.clear();
+        return MMW_OK;
+    }
+    void clear() { for (int i = 0; i < KT_NSLOT; ++i) { total_us[i] = 0; count[i] = 0; } }
+};
+
 inline int grid_rows(int rows) {  // one wavefront per row, 4 rows per workgroup, grid-stride beyond the cap
     int g = (rows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     if (g < 1) g = 1;
