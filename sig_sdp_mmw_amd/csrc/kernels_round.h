@@ -1,0 +1,161 @@
+// Device kernels for the randomized vector rounding, sdp_solver.rounding_one_attempt
+// (sim_src/alg/sdp_solver.py:27-107): user visiting order, the Gaussian projection inprod = randv gX^T
+// on the fp64 matrix cores (the one dense contraction of the path), per-user slot preference order and
+// the greedy feasible slot assignment.  All arithmetic in float64: the outputs are integers that must
+// agree exactly with the reference on identical inputs.
+#pragma once
+#include "device_utils.h"
+
+namespace mmw {
+
+// ---- ||gX_k||_2 per user (sdp_solver.py:51) ---------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_row_norms_f64(int K, int Dp, const double* __restrict__ gX, double* __restrict__ nrm) {
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    for (int row = blockIdx.x * WAVES_PER_BLOCK + wib; row < K; row += gridDim.x * WAVES_PER_BLOCK) {
+        double s = 0.0;
+        for (int c = lane; c < Dp; c += WAVE) {
+            const double x = gX[(size_t)row * Dp + c];
+            s += x * x;
+        }
+        s = wave_sum(s);
+        if (lane == 0) nrm[row] = sqrt(s);
+    }
+}
+
+// ---- order = argsort(-key): rank by counting, ties by lower index (stable) --------------------
+// rank[k] = #{ j : key[j] > key[k]  or (key[j] == key[k] and j < k) };  order[rank[k]] = k
+__global__ __launch_bounds__(BLOCK) void k_rank_desc(int n, const double* __restrict__ key, int* __restrict__ order) {
+    __shared__ double tile[BLOCK];
+    const int k = blockIdx.x * BLOCK + threadIdx.x;
+    const double mine = k < n ? key[k] : 0.0;
+    int r = 0;
+    for (int j0 = 0; j0 < n; j0 += BLOCK) {
+        const int j = j0 + threadIdx.x;
+        tile[threadIdx.x] = j < n ? key[j] : 0.0;
+        __syncthreads();
+        const int lim = n - j0 < BLOCK ? n - j0 : BLOCK;
+        for (int t = 0; t < lim; ++t) {
+            const double o = tile[t];
+            r += (o > mine) || (o == mine && (j0 + t) < k);
+        }
+        __syncthreads();
+    }
+    if (k < n) order[r] = k;
+}
+
+// ---- projection on the fp64 matrix cores -------------------------------------------------------
+// P[b][k][z] = sum_d randv[b][z][d] * gX[k][d].  One wavefront owns a 16(z) x 16(users) tile and walks
+// the D' dimension 4 at a time with v_mfma_f64_16x16x4_f64: lane l feeds A[i = l&15][kk = l>>4] and
+// B[kk = l>>4][j = l&15]; its 4 results are rows (l>>4) + 4r, column l&15 of the tile.
+// The 16 x DT slabs of both operands are staged through LDS with coalesced row reads (DT = 64 columns).
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int PROJ_DT = 64;
+__global__ __launch_bounds__(BLOCK) void k_project_mfma(int K, int Z, int Dp, const double* __restrict__ gX,
+                                                        const double* __restrict__ randv, double* __restrict__ P) {
+    // block = 4 waves: 16 slots x 64 users; blockIdx.x -> user tile, blockIdx.y -> slot tile, blockIdx.z -> batch
+    __shared__ double sA[16][PROJ_DT + 1];       // randv rows z0..z0+15
+    __shared__ double sB[64][PROJ_DT + 1];       // gX rows u0..u0+63
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int u0 = blockIdx.x * 64, z0 = blockIdx.y * 16, b = blockIdx.z;
+    const double* R = randv + (size_t)b * Z * Dp;
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    const int i = lane & 15, kk = lane >> 4;
+    for (int d0 = 0; d0 < Dp; d0 += PROJ_DT) {
+        for (int t = threadIdx.x; t < 16 * PROJ_DT; t += BLOCK) {
+            const int r = t / PROJ_DT, c = t % PROJ_DT;
+            sA[r][c] = (z0 + r < Z && d0 + c < Dp) ? R[(size_t)(z0 + r) * Dp + d0 + c] : 0.0;
+        }
+        for (int t = threadIdx.x; t < 64 * PROJ_DT; t += BLOCK) {
+            const int r = t / PROJ_DT, c = t % PROJ_DT;
+            sB[r][c] = (u0 + r < K && d0 + c < Dp) ? gX[(size_t)(u0 + r) * Dp + d0 + c] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int d = 0; d < PROJ_DT; d += 4) {
+            const double a = sA[i][d + kk];
+            const double bb = sB[wib * 16 + i][d + kk];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int user = u0 + wib * 16 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int z = z0 + (lane >> 4) + 4 * r;
+        if (user < K && z < Z) P[((size_t)b * K + user) * Z + z] = acc[r];
+    }
+}
+
+// ---- per-user preference order: pref[b][k][rank of slot z] = z, descending inprod, ties by lower z
+__global__ __launch_bounds__(BLOCK) void k_slot_pref(int K, int Z, const double* __restrict__ P, int* __restrict__ pref) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* row = reinterpret_cast<double*>(smem_raw);  // [Z]
+    const size_t base = ((size_t)blockIdx.y * K + blockIdx.x) * Z;
+    for (int z = threadIdx.x; z < Z; z += BLOCK) row[z] = P[base + z];
+    __syncthreads();
+    for (int z = threadIdx.x; z < Z; z += BLOCK) {
+        const double mine = row[z];
+        int r = 0;
+        for (int j = 0; j < Z; ++j) r += (row[j] > mine) || (row[j] == mine && j < z);
+        pref[base + r] = z;
+    }
+}
+
+// ---- greedy feasible assignment (sdp_solver.py:70-101): one workgroup per attempt ---------------
+// Users are visited in `order`; user k takes the first slot of its preference list where
+//   (a) the interference already accumulated at k stays within h_max[k],
+//   (b) adding k's emission keeps every current member n of the slot that k reaches within h_max[n],
+//   (c) no current member shares an access point with k.
+// gain_sum[z][n] accumulates S[k'][n] over the members k' of slot z in assignment order, exactly like
+// the reference's dense row adds (sdp_solver.py:94) restricted to the nonzeros.
+__global__ __launch_bounds__(BLOCK) void k_greedy(int K, int Z, const int* __restrict__ order, const int* __restrict__ pref_all,
+                                                  const int* __restrict__ so_indptr, const int* __restrict__ so_indices,
+                                                  const double* __restrict__ so_data, const int* __restrict__ q_indptr,
+                                                  const int* __restrict__ q_indices, const double* __restrict__ h_max,
+                                                  double* __restrict__ gain_all, int* __restrict__ slot_all, int* __restrict__ rem) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    int* bad = reinterpret_cast<int*>(smem_raw);  // [Z]
+    __shared__ int best;
+    __shared__ int unassigned;
+    const int b = blockIdx.x;
+    const int* pref = pref_all + (size_t)b * K * Z;
+    double* gain = gain_all + (size_t)b * Z * K;
+    int* slot = slot_all + (size_t)b * K;
+    if (threadIdx.x == 0) unassigned = 0;
+    for (int kk = 0; kk < K; ++kk) {
+        const int k = order[kk];
+        for (int z = threadIdx.x; z < Z; z += BLOCK) bad[z] = gain[(size_t)z * K + k] > h_max[k] ? 1 : 0;
+        if (threadIdx.x == 0) best = Z;
+        __syncthreads();
+        const int sb = so_indptr[k], se = so_indptr[k + 1];
+        for (int e = sb + threadIdx.x; e < se; e += BLOCK) {
+            const int n = so_indices[e];
+            const int zn = slot[n];
+            if (zn >= 0 && gain[(size_t)zn * K + n] + so_data[e] > h_max[n]) bad[zn] = 1;
+        }
+        for (int e = q_indptr[k] + threadIdx.x; e < q_indptr[k + 1]; e += BLOCK) {
+            const int zn = slot[q_indices[e]];
+            if (zn >= 0) bad[zn] = 1;
+        }
+        __syncthreads();
+        for (int zz = threadIdx.x; zz < Z; zz += BLOCK)
+            if (!bad[pref[(size_t)k * Z + zz]]) {
+                atomicMin(&best, zz);
+                break;  // this thread's later candidates are worse
+            }
+        __syncthreads();
+        const int zz = best;
+        if (zz < Z) {
+            const int z = pref[(size_t)k * Z + zz];
+            for (int e = sb + threadIdx.x; e < se; e += BLOCK) gain[(size_t)z * K + so_indices[e]] += so_data[e];
+            if (threadIdx.x == 0) slot[k] = z;
+        } else if (threadIdx.x == 0) {
+            unassigned++;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) rem[b] = unassigned;
+}
+
+}  // namespace mmw

@@ -112,7 +112,7 @@ template <typename T> struct Solver final : mmw_solver {
         MMW_TRY(out64.alloc(big));
         MMW_TRY(stage64.alloc((size_t)K * D));
         MMW_HIP(hipStreamSynchronize(st));
-        MMW_TRY(extras.init(this->st, &H, K));
+        MMW_TRY(extras.init(this->st, &H, K, &kt));
         return reset(nit);
     }
 
