@@ -1,0 +1,80 @@
+"""Solver base class: the randomized vector rounding on the device.
+
+Same surface as the reference's `sdp_solver` (sim_src/alg/sdp_solver.py:9-107): constructor
+`(nit, rank_radio, alpha)`, `run_with_state`, `rounding(Z, gX, state, nattempt=10)` and
+`rounding_one_attempt(Z, gX, state)` returning `(z_vec float64[K], Z, remainder)`.
+The projection, the preference ordering and the greedy slot assignment run in HIP kernels
+(`mmw_round`, include/mmw_hip.h); the host only draws the `Z x D'` projection vectors and the slots
+of users left unassigned from the global NumPy stream, in the reference's order
+(sdp_solver.py:48,105), so a seeded run consumes the stream identically.
+"""
+import numpy as np
+
+from . import _lib
+
+
+class sdp_solver:
+    def __init__(self, nit=100, rank_radio=2, alpha=1.):
+        self.nit = nit
+        self.rank_radio = rank_radio
+        self.alpha = alpha  # objective scaling factor, unused (sdp_solver.py:13)
+        self._dev = None  # (state arrays identity, _lib.Solver)
+
+    # ---- device handle keyed by the state's content identity ---------------------------------
+    _device_index = 0
+    _dtype_code = _lib.F64
+
+    def _state_key(self, state):
+        S, Q, h = state
+        return (S.shape[0], S.nnz, Q.nnz, float(S.data[:8].sum()) if S.nnz else 0.0, int(S.indices[:8].sum()) if S.nnz else 0,
+                float(np.asarray(h)[:8].sum()))
+
+    def _same_state(self, state):
+        if self._dev is None:
+            return False
+        key, held, _ = self._dev
+        if key != self._state_key(state):
+            return False
+        S, Q, h = state
+        S0, Q0, h0 = held
+        return (S is S0 or (np.array_equal(S.indptr, S0.indptr) and np.array_equal(S.indices, S0.indices) and
+                            np.array_equal(S.data, S0.data))) and \
+               (Q is Q0 or (np.array_equal(Q.indptr, Q0.indptr) and np.array_equal(Q.indices, Q0.indices))) and \
+               np.array_equal(np.asarray(h), np.asarray(h0))
+
+    def _device_solver(self, Z, state, nit=1, eta=0.1, need_loop=False):
+        """A device handle holding `state` (reused across the binary search's solve/rounding pairs)."""
+        if not need_loop and self._same_state(state):
+            return self._dev[2]
+        if self._dev is not None:
+            self._dev[2].close()
+        s = _lib.Solver(max(int(Z), 2), state, max(int(nit), 1), eta, rank_radio=self.rank_radio, dtype=self._dtype_code,
+                        device=self._device_index)
+        self._dev = (self._state_key(state), state, s)
+        return s
+
+    def run_with_state(self, bs_iteration, Z, state):
+        pass
+
+    def rounding(self, Z, gX, state, nattempt=10):
+        z_vec = None
+        remainder = None
+        for n in range(nattempt):
+            z_vec, Z, remainder = self.rounding_one_attempt(Z, gX, state)
+            if remainder == 0:
+                return z_vec, Z, remainder
+        return z_vec, Z, remainder
+
+    def rounding_one_attempt(self, Z, gX, state):
+        gX = np.ascontiguousarray(gX, dtype=np.float64)
+        D = gX.shape[1]
+        randv = np.random.randn(Z, D)
+        randv = randv / np.linalg.norm(randv, axis=1, keepdims=True)
+        solver = self._device_solver(Z, state)
+        z, rem = solver.round(int(Z), gX, randv[None])
+        z = z[0]
+        not_assigned = z < 0
+        z_vec = z.astype(np.float64)
+        if np.any(not_assigned):
+            z_vec[not_assigned] = np.random.randint(Z, size=int(not_assigned.sum()))
+        return z_vec, Z, np.sum(not_assigned)
