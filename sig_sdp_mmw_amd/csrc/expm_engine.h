@@ -31,6 +31,21 @@ inline int make_layout(int D, int vec, BlockLayout& lay, std::string& err) {
     return MMW_OK;
 }
 
+// one launch of the CSR SpMM (any fused epilogue) for a block with layout `lay`
+template <typename T, int MODE>
+inline int spmm_launch(hipStream_t st, int K, const BlockLayout& lay, int nblk, const int* indptr, const int* col, const T* val,
+                       const T* in, T* out, T* F, const T* X2, double c1, double c2, double c3, double* partial) {
+    const size_t sh = MODE == SPMM_LANCZOS ? (size_t)WAVES_PER_BLOCK * lay.Dpad * sizeof(double) : 0;
+    switch (lay.NCH) {
+        case 1: hipLaunchKernelGGL((k_spmm<T, 1, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, X2, c1, c2, c3, partial); break;
+        case 2: hipLaunchKernelGGL((k_spmm<T, 2, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, X2, c1, c2, c3, partial); break;
+        case 3: hipLaunchKernelGGL((k_spmm<T, 3, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, X2, c1, c2, c3, partial); break;
+        default: hipLaunchKernelGGL((k_spmm<T, 4, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, X2, c1, c2, c3, partial); break;
+    }
+    MMW_HIP(hipGetLastError());
+    return MMW_OK;
+}
+
 template <typename T> struct ExpmEngine {
     hipStream_t st = nullptr;
     int K = 0;
@@ -90,17 +105,9 @@ template <typename T> struct ExpmEngine {
     }
 
     template <int MODE> int launch_spmm(const T* in, T* out, T* F, double ascale, double shift, double inv_k) {
-        const size_t sh = MODE == SPMM_LANCZOS ? (size_t)WAVES_PER_BLOCK * lay.Dpad * sizeof(double) : 0;
         MMW_TRY(kbegin(KT_SPMM));
-        switch (lay.NCH) {
-            case 1: hipLaunchKernelGGL((k_spmm<T, 1, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, ascale, shift, inv_k, partial.p); break;
-            case 2: hipLaunchKernelGGL((k_spmm<T, 2, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, ascale, shift, inv_k, partial.p); break;
-            case 3: hipLaunchKernelGGL((k_spmm<T, 3, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, ascale, shift, inv_k, partial.p); break;
-            default: hipLaunchKernelGGL((k_spmm<T, 4, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, ascale, shift, inv_k, partial.p); break;
-        }
-        MMW_TRY(kend());
-        MMW_HIP(hipGetLastError());
-        return MMW_OK;
+        MMW_TRY((spmm_launch<T, MODE>(st, K, lay, nblk, indptr, col, val, in, out, F, nullptr, ascale, shift, inv_k, partial.p)));
+        return kend();
     }
     int colreduce(int nb) {
         hipLaunchKernelGGL(k_colreduce, dim3((lay.Dpad + 15) / 16), dim3(BLOCK), 0, st, nb, lay.Dpad, partial.p, colsum.p);

@@ -1,0 +1,303 @@
+// Host orchestration of
+//   * the epilogue factor (sim_src/alg/mmw.py:202-216): top-`rank` (largest |eigenvalue| = singular value)
+//     invariant subspace of the averaged X by Chebyshev-filtered block subspace iteration on A^2 with
+//     Rayleigh-Ritz, all linear algebra on the device (CSR SpMM + fp64-MFMA Gram / tall GEMM + Jacobi);
+//   * the LOG_GAP branch (mmw.py:79-117): max violation at Xbar and K * lambda_min(L(Ybar)) by a device
+//     Lanczos recurrence whose small tridiagonal is examined on the host (Sturm bisection).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "expm_engine.h"
+#include "kernels_dense.h"
+#include "kernels_loop.h"
+#include "runtime.h"
+
+namespace mmw {
+
+// smallest eigenvalue of the symmetric tridiagonal (a[0..n), b[0..n-1)) by bisection, and the residual
+// bound |b_last * s_n| of its Ritz vector (s = eigenvector of T, by inverse iteration).
+inline double tridiag_min_eig(const std::vector<double>& a, const std::vector<double>& b, int n, double* last_comp) {
+    double lo = 1e300, hi = -1e300;
+    for (int i = 0; i < n; ++i) {
+        const double r = (i > 0 ? std::fabs(b[i - 1]) : 0.0) + (i + 1 < n ? std::fabs(b[i]) : 0.0);
+        lo = std::min(lo, a[i] - r);
+        hi = std::max(hi, a[i] + r);
+    }
+    auto count_below = [&](double x) {  // number of eigenvalues < x (Sturm sequence)
+        int cnt = 0;
+        double q = a[0] - x;
+        if (q < 0) ++cnt;
+        for (int i = 1; i < n; ++i) {
+            const double den = std::fabs(q) < 1e-300 ? (q < 0 ? -1e-300 : 1e-300) : q;
+            q = a[i] - x - b[i - 1] * b[i - 1] / den;
+            if (q < 0) ++cnt;
+        }
+        return cnt;
+    };
+    double l = lo, h = hi;
+    for (int it = 0; it < 200 && h - l > 4e-16 * std::max(std::fabs(l), std::fabs(h)); ++it) {
+        const double m = 0.5 * (l + h);
+        if (count_below(m) >= 1) h = m;
+        else l = m;
+    }
+    const double theta = 0.5 * (l + h);
+    if (last_comp) {  // inverse iteration (T - theta' I) s = s_prev, Thomas algorithm with a tiny shift
+        std::vector<double> s(n, 1.0 / std::sqrt((double)n)), d(n), c(n), rhs(n);
+        const double sh = theta - 1e-10 * std::max(1.0, std::fabs(hi - lo));
+        for (int rep = 0; rep < 3; ++rep) {
+            rhs = s;
+            double piv = a[0] - sh;
+            if (std::fabs(piv) < 1e-300) piv = 1e-300;
+            d[0] = piv;
+            for (int i = 1; i < n; ++i) {
+                c[i - 1] = b[i - 1] / d[i - 1];
+                d[i] = a[i] - sh - c[i - 1] * b[i - 1];
+                if (std::fabs(d[i]) < 1e-300) d[i] = 1e-300;
+                rhs[i] -= c[i - 1] * rhs[i - 1];
+            }
+            s[n - 1] = rhs[n - 1] / d[n - 1];
+            for (int i = n - 2; i >= 0; --i) s[i] = (rhs[i] - b[i] * s[i + 1]) / d[i];
+            double nn = 0;
+            for (double v : s) nn += v * v;
+            nn = std::sqrt(nn);
+            for (double& v : s) v /= nn;
+        }
+        *last_comp = s[n - 1];
+    }
+    return theta;
+}
+
+template <typename T> struct DenseWork {
+    hipStream_t st = nullptr;
+    DevBuf<double> G, Q, Q2, Gpart, cs, diag, dscale, off, scale;
+    DevBuf<int> perm;
+    int bcap = 0;
+    int ensure(int b, int nslice) {
+        if (b <= bcap && Gpart.n >= (size_t)nslice * b * b) return MMW_OK;
+        bcap = std::max(b, bcap);
+        const size_t bb = (size_t)bcap * bcap;
+        MMW_TRY(G.alloc(bb)); MMW_TRY(Q.alloc(bb)); MMW_TRY(Q2.alloc(bb)); MMW_TRY(Gpart.alloc((size_t)nslice * bb));
+        MMW_TRY(cs.alloc(bcap + 2)); MMW_TRY(diag.alloc(bcap)); MMW_TRY(dscale.alloc(bcap)); MMW_TRY(off.alloc(2));
+        MMW_TRY(scale.alloc(bcap)); MMW_TRY(perm.alloc(bcap));
+        return MMW_OK;
+    }
+    static void gram_geometry(int K, int b, int& nslice, int& rps) {
+        const int tiles = ((b + 63) / 64) * ((b + 15) / 16);
+        nslice = std::max(1, std::min(16, (1024 + tiles - 1) / tiles));
+        rps = (K + nslice - 1) / nslice;
+        rps = (rps + 3) / 4 * 4;
+        nslice = (K + rps - 1) / rps;
+    }
+    // G = V^T W  (b x b)
+    int gram(int K, int b, int ld, const T* V, const T* W, bool sym) {
+        int nslice, rps;
+        gram_geometry(K, b, nslice, rps);
+        MMW_TRY(ensure(b, 16));
+        hipLaunchKernelGGL((k_gram<T>), dim3((b + 63) / 64, (b + 15) / 16, nslice), dim3(WAVE), 0, st, K, b, ld, V, W, rps, Gpart.p);
+        hipLaunchKernelGGL(k_gram_reduce, dim3(grid_elems((size_t)b * b)), dim3(BLOCK), 0, st, b, nslice, Gpart.p, G.p, sym ? 1 : 0);
+        MMW_HIP(hipGetLastError());
+        return MMW_OK;
+    }
+    // in-place Jacobi of G (b x b) -> eigenvalues on the diagonal (copied to diag), eigenvectors in Q
+    int jacobi(int b, double rel_tol, int max_sweeps, int* sweeps_done = nullptr) {
+        const int n = (b % 2 == 0) ? b : b + 1;
+        hipLaunchKernelGGL(k_set_eye, dim3(grid_elems((size_t)b * b)), dim3(BLOCK), 0, st, b, Q.p);
+        const int half = n / 2;
+        const int gp = (half + 63) / 64;
+        const int ga = grid_elems((size_t)std::max(half * half, b * half));
+        double h_off[2] = {0, 0};
+        int sw = 0;
+        for (; sw < max_sweeps; ++sw) {
+            hipLaunchKernelGGL(k_offdiag, dim3(1), dim3(BLOCK), 0, st, b, G.p, off.p);
+            MMW_HIP(hipMemcpyAsync(h_off, off.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+            MMW_HIP(hipStreamSynchronize(st));
+            if (!(std::sqrt(h_off[0]) > rel_tol * h_off[1] * std::sqrt((double)b)) || b < 2) break;
+            for (int r = 0; r < n - 1; ++r) {
+                hipLaunchKernelGGL(k_jacobi_params, dim3(gp), dim3(64), 0, st, b, n, r, G.p, cs.p, 0.0);
+                hipLaunchKernelGGL(k_jacobi_apply, dim3(ga), dim3(BLOCK), 0, st, b, n, r, G.p, Q.p, cs.p);
+            }
+            MMW_HIP(hipGetLastError());
+        }
+        if (sweeps_done) *sweeps_done = sw;
+        hipLaunchKernelGGL(k_get_diag, dim3(grid_elems(b)), dim3(BLOCK), 0, st, b, G.p, diag.p);
+        MMW_HIP(hipGetLastError());
+        return MMW_OK;
+    }
+    // Vout = V * Qmat[b x n]
+    int gemm(int K, int b, int n, int ld, const T* V, const double* Qmat, int ldq, T* Vout) {
+        hipLaunchKernelGGL((k_gemm_tall<T>), dim3((K + 63) / 64, (n + 63) / 64), dim3(BLOCK), 0, st, K, b, n, ld, V, ldq, Qmat, ld, Vout);
+        MMW_HIP(hipGetLastError());
+        return MMW_OK;
+    }
+};
+
+template <typename T> struct Factorizer {
+    hipStream_t st = nullptr;
+    KernelTimers* kt = nullptr;
+    int K = 0;
+    DenseWork<T> dw;
+    DevBuf<T> V, W, Y1, Y2;      // K x ld blocks
+    DevBuf<double> partial, colsum, rho_part, out64;
+    std::vector<double> last;    // [K*rank]
+    int last_rank = 0;
+    int outer_done = 0;
+    double last_resid = 0.0;
+
+    int init(hipStream_t s, int K_, KernelTimers* k) {
+        st = s; K = K_; kt = k; dw.st = s;
+        return MMW_OK;
+    }
+
+    // V <- V * (D Q Lambda^{-1/2}) twice: columns orthonormal to rounding
+    int orthonormalise(int b, int ld, DevBuf<T>& A, DevBuf<T>& B, double eps) {
+        for (int pass = 0; pass < 2; ++pass) {
+            MMW_TRY(dw.gram(K, b, ld, A.p, A.p, true));
+            hipLaunchKernelGGL(k_scale_sym, dim3(grid_elems(b)), dim3(BLOCK), 0, st, b, dw.G.p, dw.dscale.p);
+            hipLaunchKernelGGL(k_apply_scale_sym, dim3(grid_elems((size_t)b * b)), dim3(BLOCK), 0, st, b, dw.G.p, dw.dscale.p);
+            MMW_TRY(dw.jacobi(b, 1e-15, 30));
+            hipLaunchKernelGGL(k_orth_factor, dim3(grid_elems((size_t)b * b)), dim3(BLOCK), 0, st, b, dw.Q.p, dw.dscale.p, dw.diag.p, eps,
+                               (double)b, dw.Q2.p);
+            MMW_HIP(hipMemsetAsync(B.p, 0, (size_t)K * ld * sizeof(T), st));
+            MMW_TRY(dw.gemm(K, b, b, ld, A.p, dw.Q2.p, b, B.p));
+            std::swap(A.p, B.p);
+        }
+        return MMW_OK;
+    }
+
+    // factor of A = ascale * (values `val` on the pattern).  out: K*rank float64 (host)
+    int run(const int* indptr, const int* col, const T* val, double ascale, int rank, uint64_t seed, double* out) {
+        if (rank < 1 || rank >= K + 1) return fail(MMW_ERR_ARG, "mmw_factor: rank must be in [1, K]");
+        const bool f32 = sizeof(T) == 4;
+        const double tol = f32 ? 2e-5 : 1e-9;
+        int b = std::min(K, rank + std::max(16, rank / 4));
+        BlockLayout lay;
+        std::string err;
+        if (make_layout(b, V16<T>::N, lay, err) != MMW_OK) return fail(MMW_ERR_ARG, "mmw_factor: " + err);
+        const int ld = lay.Dpad;
+        const size_t bs = (size_t)K * ld;
+        const int nblk = grid_rows(K);
+        if (V.n < bs) { MMW_TRY(V.alloc(bs)); MMW_TRY(W.alloc(bs)); MMW_TRY(Y1.alloc(bs)); MMW_TRY(Y2.alloc(bs)); }
+        if (partial.n < (size_t)MAX_PART * ld) MMW_TRY(partial.alloc((size_t)MAX_PART * ld));
+        if (colsum.n < (size_t)ld) MMW_TRY(colsum.alloc(ld));
+        if (rho_part.n < (size_t)MAX_PART) MMW_TRY(rho_part.alloc(MAX_PART));
+        MMW_TRY(dw.ensure(b, 16));
+        if (kt) MMW_TRY(kt->begin(KT_FACTOR));
+        // spectral scale: ||A||_1 >= |lambda|_max
+        hipLaunchKernelGGL((k_rowabs<T>), dim3(nblk), dim3(BLOCK), 0, st, K, indptr, col, val, ascale, (const double*)nullptr, 0, rho_part.p);
+        std::vector<double> hp(nblk);
+        MMW_HIP(hipMemcpyAsync(hp.data(), rho_part.p, nblk * sizeof(double), hipMemcpyDeviceToHost, st));
+        MMW_HIP(hipStreamSynchronize(st));
+        const double rho = *std::max_element(hp.begin(), hp.end());
+        // random start block (rows of unit norm; any full-rank start works)
+        hipLaunchKernelGGL((k_sketch_rng<T>), dim3(nblk), dim3(BLOCK), 0, st, K, b, ld, seed ^ 0x9E3779B97F4A7C15ull, 0u, V.p);
+        MMW_TRY(orthonormalise(b, ld, V, W, 1e-14));
+        std::vector<double> theta(b), res(b), hres((size_t)64 * b);
+        std::vector<int> perm(b);
+        std::vector<double> ones(b, 1.0);
+        MMW_HIP(hipMemcpyAsync(dw.scale.p, ones.data(), b * sizeof(double), hipMemcpyHostToDevice, st));
+        const int max_outer = 40;
+        int outer = 0;
+        bool done = false;
+        int degree = 8;
+        for (; outer < max_outer && !done; ++outer) {
+            // ---- Rayleigh-Ritz on span(V)
+            MMW_TRY((spmm_launch<T, SPMM_PLAIN>(st, K, lay, nblk, indptr, col, val, V.p, W.p, nullptr, nullptr, ascale, 0.0, 0.0, nullptr)));
+            MMW_TRY(dw.gram(K, b, ld, V.p, W.p, true));
+            MMW_TRY(dw.jacobi(b, 1e-15, 30));
+            MMW_HIP(hipMemcpyAsync(theta.data(), dw.diag.p, b * sizeof(double), hipMemcpyDeviceToHost, st));
+            MMW_HIP(hipStreamSynchronize(st));
+            std::iota(perm.begin(), perm.end(), 0);
+            std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) { return std::fabs(theta[x]) > std::fabs(theta[y]); });
+            MMW_HIP(hipMemcpyAsync(dw.perm.p, perm.data(), b * sizeof(int), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_select_cols, dim3(grid_elems((size_t)b * b)), dim3(BLOCK), 0, st, b, b, dw.Q.p, dw.perm.p, dw.scale.p, dw.Q2.p);
+            MMW_HIP(hipMemsetAsync(Y1.p, 0, bs * sizeof(T), st));
+            MMW_HIP(hipMemsetAsync(Y2.p, 0, bs * sizeof(T), st));
+            MMW_TRY(dw.gemm(K, b, b, ld, V.p, dw.Q2.p, b, Y1.p));
+            MMW_TRY(dw.gemm(K, b, b, ld, W.p, dw.Q2.p, b, Y2.p));
+            std::swap(V.p, Y1.p);
+            std::swap(W.p, Y2.p);
+            std::vector<double> ths(b);
+            for (int i = 0; i < b; ++i) ths[i] = theta[perm[i]];
+            theta = ths;
+            // residual norms ||A v - theta v|| per Ritz pair
+            MMW_HIP(hipMemcpyAsync(dw.diag.p, theta.data(), b * sizeof(double), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL((k_resid_colsq<T>), dim3(64), dim3(BLOCK), 0, st, K, b, ld, W.p, V.p, dw.diag.p, partial.p);
+            MMW_HIP(hipMemcpyAsync(hres.data(), partial.p, (size_t)64 * b * sizeof(double), hipMemcpyDeviceToHost, st));
+            MMW_HIP(hipStreamSynchronize(st));
+            double worst = 0.0;
+            for (int c = 0; c < b; ++c) {
+                double s = 0.0;
+                for (int q = 0; q < 64; ++q) s += hres[(size_t)q * b + c];
+                res[c] = std::sqrt(s);
+                if (c < rank) worst = std::max(worst, res[c]);
+            }
+            const double scale_top = std::max(std::fabs(theta[0]), 1e-300);
+            last_resid = worst / scale_top;
+            if (b >= K || last_resid <= tol) {
+                done = true;
+                break;
+            }
+            // ---- Chebyshev filter on B = A^2 damping [0, cut], cut = smallest Ritz value of B in the block
+            const double mu_top = theta[0] * theta[0];
+            double cut = theta[b - 1] * theta[b - 1];
+            cut = std::max(cut, 1e-12 * mu_top);
+            cut = std::min(cut, 0.999 * theta[rank - 1] * theta[rank - 1] + 1e-300);
+            const double e = 0.5 * cut, cen = 0.5 * cut;
+            const double a0 = std::max(mu_top, rho * rho * 1e-30);
+            double sigma1 = e / (a0 - cen), sigma = sigma1;
+            // Y = sigma1/e (B V - cen V): T1 = A V (already W); Ycur = c1 * A W + c2 * V
+            MMW_TRY((spmm_launch<T, SPMM_AXPBY>(st, K, lay, nblk, indptr, col, val, W.p, Y1.p, V.p, V.p, ascale * sigma1 / e, -cen * sigma1 / e, 0.0, nullptr)));
+            // V = previous, Y1 = current
+            T* prev = V.p;
+            T* cur = Y1.p;
+            T* nxt = Y2.p;
+            for (int i = 2; i <= degree; ++i) {
+                const double sigma2 = 1.0 / (2.0 / sigma1 - sigma);
+                MMW_TRY((spmm_launch<T, SPMM_PLAIN>(st, K, lay, nblk, indptr, col, val, cur, W.p, nullptr, nullptr, ascale, 0.0, 0.0, nullptr)));
+                // nxt = 2 sigma2/e (A W - cen cur) - sigma sigma2 prev
+                MMW_TRY((spmm_launch<T, SPMM_AXPBY>(st, K, lay, nblk, indptr, col, val, W.p, nxt, cur, prev, ascale * 2.0 * sigma2 / e,
+                                                    -cen * 2.0 * sigma2 / e, -sigma * sigma2, nullptr)));
+                T* t = prev;
+                prev = cur;
+                cur = nxt;
+                nxt = t;
+                sigma = sigma2;
+            }
+            // move the filtered block into V, keep the three buffers distinct
+            if (cur != V.p) {
+                T* oldV = V.p;
+                V.p = cur;
+                if (cur == Y1.p) Y1.p = oldV; else Y2.p = oldV;
+            }
+            MMW_TRY(orthonormalise(b, ld, V, W, 1e-14));
+            degree = std::min(40, degree + 4);
+        }
+        outer_done = outer;
+        if (kt) MMW_TRY(kt->end());
+        if (!done && last_resid > 100 * tol)
+            return fail(MMW_ERR_STATE, "mmw_factor: subspace iteration did not converge (relative residual " + std::to_string(last_resid) + ")");
+        // ---- X_half = V[:, top rank] sqrt|theta|, columns in ascending |theta| (svds order, mmw.py:215-216)
+        std::vector<int> sel(rank);
+        std::vector<double> sc(rank);
+        for (int c = 0; c < rank; ++c) {
+            sel[c] = rank - 1 - c;
+            sc[c] = std::sqrt(std::fabs(theta[rank - 1 - c]));
+        }
+        if (out64.n < (size_t)K * rank) MMW_TRY(out64.alloc((size_t)K * rank));
+        MMW_HIP(hipMemcpyAsync(dw.perm.p, sel.data(), rank * sizeof(int), hipMemcpyHostToDevice, st));
+        MMW_HIP(hipMemcpyAsync(dw.diag.p, sc.data(), rank * sizeof(double), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL((k_export_factor<T>), dim3(grid_elems((size_t)K * rank)), dim3(BLOCK), 0, st, K, rank, ld, V.p, dw.perm.p, dw.diag.p, out64.p);
+        MMW_HIP(hipGetLastError());
+        last.resize((size_t)K * rank);
+        MMW_HIP(hipMemcpyAsync(last.data(), out64.p, (size_t)K * rank * sizeof(double), hipMemcpyDeviceToHost, st));
+        MMW_HIP(hipStreamSynchronize(st));
+        last_rank = rank;
+        // restore the unit column scales used by k_select_cols
+        if (out) memcpy(out, last.data(), last.size() * sizeof(double));
+        return MMW_OK;
+    }
+};
+
+}  // namespace mmw

@@ -1,0 +1,313 @@
+// Small dense building blocks for the epilogue factor (top-|lambda| invariant subspace of the averaged X,
+// replacing scipy.sparse.linalg.svds at sim_src/alg/mmw.py:215) and the duality-gap Lanczos
+// (eigsh at mmw.py:115):
+//   gram      G = V^T W            (b x b, reduction over the K rows)     -- fp64 matrix cores
+//   gemm_tall C = V Q              (K x b times b x n)                    -- fp64 matrix cores, LDS tiles
+//   jacobi    H = Q Theta Q^T      (parallel cyclic Jacobi, two launches per round)
+// plus the element-wise helpers around them.  These are the dense contractions of the path; everything
+// here accumulates in float64 whatever the block dtype T is.
+#pragma once
+#include "device_utils.h"
+
+namespace mmw {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// ---- G_part[slice] (b x b) += V[rows of slice]^T W[rows of slice] ---------------------------------
+// grid = (ceil(b/64) j-tiles, ceil(b/16) i-tiles, nslice); one wavefront per workgroup tile 16(i) x 64(j).
+// v_mfma_f64_16x16x4_f64: lane l feeds A[i = l&15][k = l>>4] = V[k][i] and B[k][j = l&15] = W[k][j]:
+// both are 16 consecutive elements of a block row -> coalesced straight from global memory.
+template <typename T>
+__global__ __launch_bounds__(WAVE) void k_gram(int K, int b, int ld, const T* __restrict__ V, const T* __restrict__ W,
+                                               int rows_per_slice, double* __restrict__ Gpart) {
+    const int lane = threadIdx.x;
+    const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 16, sl = blockIdx.z;
+    const int r_beg = sl * rows_per_slice;
+    const int r_end = min(K, r_beg + rows_per_slice);
+    const int li = lane & 15, lk = lane >> 4;
+    d4 acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = (d4){0.0, 0.0, 0.0, 0.0};
+    const bool iok = i0 + li < b;
+    bool jok[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) jok[n] = j0 + n * 16 + li < b;
+    for (int r = r_beg; r < r_end; r += 4) {
+        const int row = r + lk;
+        const bool rok = row < r_end;
+        const double a = (rok && iok) ? (double)V[(size_t)row * ld + i0 + li] : 0.0;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const double bb = (rok && jok[n]) ? (double)W[(size_t)row * ld + j0 + n * 16 + li] : 0.0;
+            acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[n], 0, 0, 0);
+        }
+    }
+    double* G = Gpart + (size_t)sl * b * b;
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + lk + 4 * q, j = j0 + n * 16 + li;
+            if (i < b && j < b) G[(size_t)i * b + j] = acc[n][q];
+        }
+}
+// G = sum over slices, optionally symmetrised
+__global__ __launch_bounds__(BLOCK) void k_gram_reduce(int b, int nslice, const double* __restrict__ Gpart, double* __restrict__ G,
+                                                       int symmetrise) {
+    const int n = b * b;
+    for (int o = blockIdx.x * BLOCK + threadIdx.x; o < n; o += gridDim.x * BLOCK) {
+        const int i = o / b, j = o % b;
+        double s = 0.0;
+        for (int t = 0; t < nslice; ++t) s += Gpart[(size_t)t * n + o];
+        if (symmetrise) {
+            double u = 0.0;
+            for (int t = 0; t < nslice; ++t) u += Gpart[(size_t)t * n + (size_t)j * b + i];
+            s = 0.5 * (s + u);
+        }
+        G[o] = s;
+    }
+}
+
+// ---- C[K x n] = V[K x b] * Q[b x n] (Q float64 row-major, leading dim ldq) -------------------------
+// workgroup = 4 waves = 64 rows x 64 columns; the k dimension is walked in LDS tiles of 16.
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_gemm_tall(int K, int b, int n, int ldv, const T* __restrict__ V, int ldq,
+                                                     const double* __restrict__ Q, int ldc, T* __restrict__ C) {
+    __shared__ double sA[64][17];
+    __shared__ double sB[16][65];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int li = lane & 15, lk = lane >> 4;
+    d4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < b; k0 += 16) {
+        for (int t = threadIdx.x; t < 64 * 16; t += BLOCK) {
+            const int r = t >> 4, c = t & 15;
+            sA[r][c] = (r0 + r < K && k0 + c < b) ? (double)V[(size_t)(r0 + r) * ldv + k0 + c] : 0.0;
+        }
+        for (int t = threadIdx.x; t < 16 * 64; t += BLOCK) {
+            const int r = t >> 6, c = t & 63;
+            sB[r][c] = (k0 + r < b && c0 + c < n) ? Q[(size_t)(k0 + r) * ldq + c0 + c] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 4) {
+            const double a = sA[wib * 16 + li][kk + lk];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sB[kk + lk][t * 16 + li], acc[t], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = r0 + wib * 16 + lk + 4 * q, c = c0 + t * 16 + li;
+            if (r < K && c < n) C[(size_t)r * ldc + c] = (T)acc[t][q];
+        }
+}
+
+// ---- parallel cyclic Jacobi on a symmetric b x b matrix H (float64), eigenvectors accumulated in Q --
+// Round-robin ("tournament") ordering: n = even padded size, round r pairs up all indices disjointly.
+__device__ __forceinline__ void jacobi_pair(int n, int r, int i, int& p, int& q) {
+    // positions 0..n-1 around a table, index n-1 fixed; standard circle method
+    const int m = n - 1;
+    if (i == 0) {
+        p = m;
+        q = r % m;
+    } else {
+        p = (r + i) % m;
+        q = (r - i + m) % m;
+    }
+    if (p > q) {
+        const int t = p;
+        p = q;
+        q = t;
+    }
+}
+// rotation parameters for every pair of round r
+__global__ void k_jacobi_params(int b, int n, int r, const double* __restrict__ H, double* __restrict__ cs, double thresh) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n / 2) return;
+    int p, q;
+    jacobi_pair(n, r, i, p, q);
+    double c = 1.0, s = 0.0;
+    if (q < b) {
+        const double apq = H[(size_t)p * b + q];
+        if (fabs(apq) > thresh) {
+            const double app = H[(size_t)p * b + p], aqq = H[(size_t)q * b + q];
+            const double tau = (aqq - app) / (2.0 * apq);
+            const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+            c = 1.0 / sqrt(1.0 + t * t);
+            s = t * c;
+        }
+    }
+    cs[2 * i] = c;
+    cs[2 * i + 1] = s;
+}
+// H <- J^T H J on 2x2 blocks (pair i, pair j);  Q <- Q J on (row x, pair j)
+__global__ __launch_bounds__(BLOCK) void k_jacobi_apply(int b, int n, int r, double* __restrict__ H, double* __restrict__ Q,
+                                                        const double* __restrict__ cs) {
+    const int half = n / 2;
+    const int total = half * half;
+    for (int o = blockIdx.x * BLOCK + threadIdx.x; o < total; o += gridDim.x * BLOCK) {
+        const int i = o / half, j = o % half;
+        int pi, qi, pj, qj;
+        jacobi_pair(n, r, i, pi, qi);
+        jacobi_pair(n, r, j, pj, qj);
+        const double ci = cs[2 * i], si = cs[2 * i + 1], cj = cs[2 * j], sj = cs[2 * j + 1];
+        const bool qi_ok = qi < b, qj_ok = qj < b;
+        // block [[h_pp, h_pq],[h_qp, h_qq]] with rows (pi, qi) and columns (pj, qj)
+        double h00 = H[(size_t)pi * b + pj];
+        double h01 = qj_ok ? H[(size_t)pi * b + qj] : 0.0;
+        double h10 = qi_ok ? H[(size_t)qi * b + pj] : 0.0;
+        double h11 = (qi_ok && qj_ok) ? H[(size_t)qi * b + qj] : 0.0;
+        // rows: J_i^T with J = [[c, s],[-s, c]]
+        const double t00 = ci * h00 - si * h10, t01 = ci * h01 - si * h11;
+        const double t10 = si * h00 + ci * h10, t11 = si * h01 + ci * h11;
+        // columns: * J_j
+        h00 = t00 * cj - t01 * sj;
+        h01 = t00 * sj + t01 * cj;
+        h10 = t10 * cj - t11 * sj;
+        h11 = t10 * sj + t11 * cj;
+        H[(size_t)pi * b + pj] = h00;
+        if (qj_ok) H[(size_t)pi * b + qj] = h01;
+        if (qi_ok) H[(size_t)qi * b + pj] = h10;
+        if (qi_ok && qj_ok) H[(size_t)qi * b + qj] = h11;
+    }
+    const int totq = b * half;
+    for (int o = blockIdx.x * BLOCK + threadIdx.x; o < totq; o += gridDim.x * BLOCK) {
+        const int x = o / half, j = o % half;
+        int pj, qj;
+        jacobi_pair(n, r, j, pj, qj);
+        if (qj >= b) continue;
+        const double cj = cs[2 * j], sj = cs[2 * j + 1];
+        const double a = Q[(size_t)x * b + pj], d = Q[(size_t)x * b + qj];
+        Q[(size_t)x * b + pj] = a * cj - d * sj;
+        Q[(size_t)x * b + qj] = a * sj + d * cj;
+    }
+}
+// off-diagonal Frobenius norm^2 and diagonal scale: out[0] = sum_{i != j} H_ij^2, out[1] = max |H_ii|
+__global__ __launch_bounds__(BLOCK) void k_offdiag(int b, const double* __restrict__ H, double* __restrict__ out) {
+    __shared__ double sh[WAVES_PER_BLOCK];
+    double s = 0.0, d = 0.0;
+    for (int o = threadIdx.x; o < b * b; o += BLOCK) {
+        const int i = o / b, j = o % b;
+        const double h = H[o];
+        if (i != j) s += h * h;
+        else d = fabs(h) > d ? fabs(h) : d;
+    }
+    s = block_sum(s, sh);
+    d = block_max(d, sh);
+    if (threadIdx.x == 0) {
+        out[0] = s;
+        out[1] = d;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_set_eye(int b, double* __restrict__ Q) {
+    for (int o = blockIdx.x * BLOCK + threadIdx.x; o < b * b; o += gridDim.x * BLOCK) Q[o] = (o / b == o % b) ? 1.0 : 0.0;
+}
+__global__ __launch_bounds__(BLOCK) void k_get_diag(int b, const double* __restrict__ H, double* __restrict__ d) {
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < b; i += gridDim.x * BLOCK) d[i] = H[(size_t)i * b + i];
+}
+// Qout[:, c] = Q[:, perm[c]] * scale[c]   (column selection / permutation / scaling of a b x b matrix -> b x n)
+__global__ __launch_bounds__(BLOCK) void k_select_cols(int b, int n, const double* __restrict__ Q, const int* __restrict__ perm,
+                                                       const double* __restrict__ scale, double* __restrict__ Qout) {
+    for (int o = blockIdx.x * BLOCK + threadIdx.x; o < b * n; o += gridDim.x * BLOCK) {
+        const int i = o / n, c = o % n;
+        Qout[o] = Q[(size_t)i * b + perm[c]] * scale[c];
+    }
+}
+// G'_{ij} = d_i G_ij d_j with d = 1/sqrt(diag G) (unit-diagonal scaling before the orthonormalising eigensolve)
+__global__ __launch_bounds__(BLOCK) void k_scale_sym(int b, double* __restrict__ G, double* __restrict__ dscale) {
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < b; i += gridDim.x * BLOCK) {
+        const double g = G[(size_t)i * b + i];
+        dscale[i] = g > 0.0 ? 1.0 / sqrt(g) : 0.0;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_apply_scale_sym(int b, double* __restrict__ G, const double* __restrict__ dscale) {
+    for (int o = blockIdx.x * BLOCK + threadIdx.x; o < b * b; o += gridDim.x * BLOCK) G[o] *= dscale[o / b] * dscale[o % b];
+}
+// Qout = diag(dscale) * Q * diag(1/sqrt(max(lambda, floor)))   -> the orthonormalising right factor
+__global__ __launch_bounds__(BLOCK) void k_orth_factor(int b, const double* __restrict__ Q, const double* __restrict__ dscale,
+                                                       const double* __restrict__ lam, double floor_rel, double lam_max,
+                                                       double* __restrict__ Qout) {
+    for (int o = blockIdx.x * BLOCK + threadIdx.x; o < b * b; o += gridDim.x * BLOCK) {
+        const int i = o / b, j = o % b;
+        double l = lam[j];
+        const double fl = floor_rel * lam_max;
+        if (!(l > fl)) l = fl;
+        Qout[o] = dscale[i] * Q[o] / sqrt(l);
+    }
+}
+// partial[block][c] = sum over the block's rows of (W[r,c] - theta[c] V[r,c])^2
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_resid_colsq(int K, int b, int ld, const T* __restrict__ W, const T* __restrict__ V,
+                                                       const double* __restrict__ theta, double* __restrict__ partial) {
+    for (int c = threadIdx.x; c < b; c += BLOCK) {
+        double s = 0.0;
+        const double th = theta[c];
+        for (int r = blockIdx.x; r < K; r += gridDim.x) {
+            const double d = (double)W[(size_t)r * ld + c] - th * (double)V[(size_t)r * ld + c];
+            s += d * d;
+        }
+        partial[(size_t)blockIdx.x * b + c] = s;
+    }
+}
+// Out = c1 * X + c2 * Y  (block axpby)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_axpby(size_t n, double c1, const T* __restrict__ X, double c2, const T* __restrict__ Y,
+                                                 T* __restrict__ Out) {
+    for (size_t o = (size_t)blockIdx.x * BLOCK + threadIdx.x; o < n; o += (size_t)gridDim.x * BLOCK)
+        Out[o] = (T)(c1 * (double)X[o] + c2 * (double)Y[o]);
+}
+
+}  // namespace mmw
+
+namespace mmw {
+// out[r, c] = V[r, sel[c]] * sc[c]   (K x rank float64, row-major)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_export_factor(int K, int rank, int ld, const T* __restrict__ V, const int* __restrict__ sel,
+                                                         const double* __restrict__ sc, double* __restrict__ out) {
+    const size_t n = (size_t)K * rank;
+    for (size_t o = (size_t)blockIdx.x * BLOCK + threadIdx.x; o < n; o += (size_t)gridDim.x * BLOCK) {
+        const int c = (int)(o % rank);
+        const size_t r = o / rank;
+        out[o] = (double)V[r * ld + sel[c]] * sc[c];
+    }
+}
+// dst = src * s
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_scaled_copy(size_t n, const T* __restrict__ src, double s, T* __restrict__ dst) {
+    for (size_t o = (size_t)blockIdx.x * BLOCK + threadIdx.x; o < n; o += (size_t)gridDim.x * BLOCK) dst[o] = (T)((double)src[o] * s);
+}
+// scal = { sum Y_D, sum Y_F, sum_k cH_k Y_H,k / norm_H,k , total } for an arbitrary weight vector Y (used at Ybar)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_ysums(int K, int E_asso, const T* __restrict__ Y, const T* __restrict__ cH,
+                                                 const T* __restrict__ inv_norm_H, double* __restrict__ scal) {
+    __shared__ double sh[WAVES_PER_BLOCK];
+    double sD = 0, sF = 0, sW = 0;
+    const int C = E_asso + 2 * K, baseH = K + E_asso;
+    for (int c = threadIdx.x; c < C; c += BLOCK) {
+        const double y = (double)Y[c];
+        if (c < K) sD += y;
+        else if (c < baseH) sF += y;
+        else sW += (double)cH[c - baseH] * y * (double)inv_norm_H[c - baseH];
+    }
+    sD = block_sum(sD, sh);
+    sF = block_sum(sF, sh);
+    sW = block_sum(sW, sh);
+    if (threadIdx.x == 0) {
+        scal[0] = sD; scal[1] = sF; scal[2] = sW; scal[3] = 1.0;
+    }
+}
+// single value: max over a partial slab
+__global__ __launch_bounds__(BLOCK) void k_max_reduce(int n, const double* __restrict__ part, double* __restrict__ out) {
+    __shared__ double sh[WAVES_PER_BLOCK];
+    double m = -1e300;
+    for (int i = threadIdx.x; i < n; i += BLOCK) m = part[i] > m ? part[i] : m;
+    m = block_max(m, sh);
+    if (threadIdx.x == 0) out[0] = m;
+}
+}  // namespace mmw

@@ -26,16 +26,17 @@ struct ExpmPlan {      // written by k_plan, read by every expm kernel
     int pad;
 };
 
-enum { SPMM_PLAIN = 0, SPMM_LANCZOS = 1, SPMM_TAYLOR = 2 };
+enum { SPMM_PLAIN = 0, SPMM_LANCZOS = 1, SPMM_TAYLOR = 2, SPMM_AXPBY = 3 };
 
 // Out = ascale * A * U (+ mode-specific fused epilogue).  One wavefront per matrix row, grid-stride.
 //   SPMM_LANCZOS: also partial[block][col] = sum_rows U[row,col] * Out[row,col]   (alpha numerators)
 //   SPMM_TAYLOR : Out = (ascale*A*U - shift*U) * inv_k ;  F += Out                (one Taylor term)
+//   SPMM_AXPBY  : Out = ascale*A*U + shift*F + inv_k*X2                           (Chebyshev recurrences)
 template <typename T, int NCH, int MODE>
 __global__ __launch_bounds__(BLOCK) void k_spmm(int K, BlockLayout lay, const int* __restrict__ indptr,
                                                 const int* __restrict__ col, const T* __restrict__ val,
                                                 const T* __restrict__ U, T* __restrict__ Out, T* __restrict__ F,
-                                                double ascale, double shift, double inv_k,
+                                                const T* __restrict__ X2, double ascale, double shift, double inv_k,
                                                 double* __restrict__ partial) {
     constexpr int VEC = V16<T>::N;
     const int lane = threadIdx.x & 63;
@@ -117,6 +118,13 @@ __global__ __launch_bounds__(BLOCK) void k_spmm(int K, BlockLayout lay, const in
                             o[v] = (T)(ascale * (double)acc[c][v]);
                             dot[c][v] += (double)u[v] * (double)o[v];
                         }
+                    } else if (MODE == SPMM_AXPBY) {
+                        T f[VEC], x2[VEC];
+                        load16(F + off, f);
+                        load16(X2 + off, x2);
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v)
+                            o[v] = (T)(ascale * (double)acc[c][v] + shift * (double)f[v] + inv_k * (double)x2[v]);
                     } else {
                         T u[VEC], f[VEC];
                         load16(U + off, u);

@@ -337,11 +337,15 @@ template <typename T> struct Solver final : mmw_solver {
     }
     int gap(double out[3]) override {
         if (host_only) return fail(MMW_ERR_STATE, "host-only handle");
-        return extras.gap(out);
+        MMW_HIP(hipSetDevice(device));
+        if (iter >= nit) return fail(MMW_ERR_STATE, "mmw_gap: call it before an iteration (the running sums then hold iter+1 terms)");
+        return extras.gap(pat(), xavg.p, yavg.p, iter + 1, out);
     }
     int factor(int32_t rank, double* out, uint64_t seed) override {
         if (host_only) return fail(MMW_ERR_STATE, "host-only handle");
-        return extras.factor(rank, out, seed);
+        MMW_HIP(hipSetDevice(device));
+        if (iter < nit) return fail(MMW_ERR_STATE, "mmw_factor: run all announced iterations first (the average divides by nit)");
+        return extras.factor(d_indptr.p, d_col.p, xavg.p, nit, rank, out, seed);
     }
     int round(int32_t Zr, int32_t Dp, const double* gX, int32_t nbatch, const double* randv, int32_t* z_out, int32_t* rem_out) override {
         if (host_only) return fail(MMW_ERR_STATE, "host-only handle");

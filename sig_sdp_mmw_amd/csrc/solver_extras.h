@@ -1,5 +1,6 @@
 // Rounding, epilogue factor and duality-gap routines that hang off a solver handle.
 #pragma once
+#include "factor.h"
 #include "kernels_round.h"
 #include "pattern.h"
 #include "runtime.h"
@@ -16,6 +17,10 @@ template <typename T> struct Extras {
     DevBuf<double> so_data, h_max;
     DevBuf<double> gX, randv, P, gain, nrm;
     DevBuf<int> pref, slot, order, rem;
+    Factorizer<T> fac;
+    // gap work
+    DevBuf<T> g_x, g_l, g_y, g_e1, g_e2, g_r, g_vec, g_tm;
+    DevBuf<double> g_part, g_scal, g_lz, g_colsum, g_trace;
 
     int init(hipStream_t s, const HostPattern* h, int K_, KernelTimers* k) {
         st = s; H = h; K = K_; kt = k;
@@ -26,16 +31,119 @@ template <typename T> struct Extras {
         MMW_TRY(q_indices.upload(H->q_indices, st));
         MMW_TRY(h_max.upload(H->h_max, st));
         MMW_HIP(hipStreamSynchronize(st));
-        return MMW_OK;
+        return fac.init(st, K, kt);
     }
     template <typename B> static int ensure(DevBuf<B>& b, size_t n) {
         if (b.n >= n && b.p) return MMW_OK;
         return b.alloc(n);
     }
 
-    int gap(double*) { return fail(MMW_ERR_STATE, "mmw_gap: not built yet"); }
-    int factor(int32_t, double*, uint64_t) { return fail(MMW_ERR_STATE, "mmw_factor: not built yet"); }
-    int read_factor(double*, int64_t) { return fail(MMW_ERR_STATE, "mmw_factor: not built yet"); }
+    // ---- LOG_GAP (mmw.py:79-117): nterms = number of X / Y terms in the running sums
+    int gap(const PatternDev<T>& P, const T* xavg, const T* yavg, int nterms, double out[3]) {
+        const size_t nnz = (size_t)P.nnzL, C = (size_t)P.C;
+        const int gr = grid_rows(K);
+        MMW_TRY(ensure(g_x, nnz)); MMW_TRY(ensure(g_l, nnz)); MMW_TRY(ensure(g_y, C)); MMW_TRY(ensure(g_e1, C)); MMW_TRY(ensure(g_e2, C));
+        MMW_TRY(ensure(g_r, K)); MMW_TRY(ensure(g_part, MAX_PART)); MMW_TRY(ensure(g_scal, 8)); MMW_TRY(ensure(g_trace, MAX_PART));
+        const double inv = 1.0 / (double)nterms;
+        hipLaunchKernelGGL((k_scaled_copy<T>), dim3(grid_elems(nnz)), dim3(BLOCK), 0, st, nnz, xavg, inv, g_x.p);
+        hipLaunchKernelGGL((k_scaled_copy<T>), dim3(grid_elems(C)), dim3(BLOCK), 0, st, C, yavg, inv, g_y.p);
+        // violations at Xbar: reuse the DUAL kernels with a zero accumulator and eta = 1 -> block maxima of e
+        MMW_HIP(hipMemsetAsync(g_e2.p, 0, C * sizeof(T), st));
+        hipLaunchKernelGGL((k_dual_rows<T>), dim3(gr), dim3(BLOCK), 0, st, P, g_x.p, g_r.p, g_e1.p);
+        hipLaunchKernelGGL((k_dual_h<T>), dim3(gr), dim3(BLOCK), 0, st, P, g_r.p, g_e1.p, g_e2.p, 1.0, g_part.p);
+        hipLaunchKernelGGL(k_max_reduce, dim3(1), dim3(BLOCK), 0, st, gr, g_part.p, g_scal.p + 4);
+        // L(Ybar) on the pattern
+        hipLaunchKernelGGL((k_ysums<T>), dim3(1), dim3(BLOCK), 0, st, K, P.E_asso, g_y.p, P.cH, P.inv_norm_H, g_scal.p);
+        MMW_HIP(hipMemsetAsync(g_l.p, 0, nnz * sizeof(T), st));
+        hipLaunchKernelGGL((k_loss<T>), dim3(gr), dim3(BLOCK), 0, st, P, g_y.p, g_scal.p, g_l.p, -1.0, g_trace.p);
+        MMW_HIP(hipGetLastError());
+        double emax = 0.0;
+        MMW_HIP(hipMemcpyAsync(&emax, g_scal.p + 4, sizeof(double), hipMemcpyDeviceToHost, st));
+        double lam = 0.0;
+        MMW_TRY(lambda_min(P.indptr, P.col, g_l.p, &lam));
+        MMW_HIP(hipStreamSynchronize(st));
+        out[0] = emax;
+        out[1] = lam * (double)K;
+        out[2] = out[0] - out[1];
+        return MMW_OK;
+    }
+
+    // smallest eigenvalue of the symmetric matrix (pattern, val): plain Lanczos (the extreme Ritz value of the
+    // three-term recurrence converges to lambda_min with or without reorthogonalisation), tridiagonal on the host
+    int lambda_min(const int* indptr, const int* col, const T* val, double* lam) {
+        BlockLayout lay;
+        std::string err;
+        MMW_TRY(make_layout(1, V16<T>::N, lay, err));
+        const int Dp = lay.Dpad;
+        const size_t bs = (size_t)K * Dp;
+        const int m_max = std::min(K, 600), chunk = 20;
+        MMW_TRY(ensure(g_vec, 3 * bs)); MMW_TRY(ensure(g_tm, bs));
+        MMW_TRY(ensure(g_lz, (size_t)4 * (m_max + 3) * Dp));
+        MMW_TRY(ensure(g_colsum, Dp));
+        DevBuf<double>& part = fac.partial;
+        if (part.n < (size_t)MAX_PART * Dp) MMW_TRY(part.alloc((size_t)MAX_PART * std::max(Dp, 4)));
+        LanczosScalars S;
+        const size_t n = (size_t)(m_max + 3) * Dp;
+        S.alpha = g_lz.p; S.beta = g_lz.p + n; S.sinv = g_lz.p + 2 * n; S.coef = g_lz.p + 3 * n;
+        const int nblk = grid_rows(K), gr = grid_rows(K * 4);
+        const size_t shcol = (size_t)BLOCK * sizeof(double);
+        auto blk = [&](int j) { return g_vec.p + (size_t)((j - 1) % 3) * bs; };
+        // deterministic start vector: Philox normals, one column
+        hipLaunchKernelGGL((k_sketch_rng<T>), dim3(nblk), dim3(BLOCK), 0, st, K, 1, Dp, 0x6a09e667f3bcc908ull, 7u, blk(1));
+        // rows are normalised to +-1 by the sketch kernel; that is a fine start vector
+        hipLaunchKernelGGL((k_colsq<T>), dim3(gr), dim3(BLOCK), shcol, st, K, Dp, blk(1), part.p);
+        hipLaunchKernelGGL(k_colreduce, dim3((Dp + 15) / 16), dim3(BLOCK), 0, st, gr, Dp, part.p, g_colsum.p);
+        hipLaunchKernelGGL(k_lz_init, dim3(1), dim3(64), 0, st, Dp, g_colsum.p, S);
+        std::vector<double> a, b, ha((size_t)(m_max + 3) * Dp), hb((size_t)(m_max + 3) * Dp);
+        const double eps = sizeof(T) == 4 ? 1e-6 : 1e-14;
+        const double tol = sizeof(T) == 4 ? 1e-5 : 1e-11;
+        double theta = 0.0;
+        int j = 1;
+        while (j <= m_max) {
+            const int jend = std::min(m_max, j + chunk - 1);
+            for (; j <= jend; ++j) {
+                MMW_TRY((spmm_launch<T, SPMM_LANCZOS>(st, K, lay, nblk, indptr, col, val, blk(j), g_tm.p, nullptr, nullptr, 1.0, 0.0, 1.0, part.p)));
+                hipLaunchKernelGGL(k_colreduce, dim3((Dp + 15) / 16), dim3(BLOCK), 0, st, nblk, Dp, part.p, g_colsum.p);
+                hipLaunchKernelGGL(k_lz_alpha, dim3(1), dim3(64), 0, st, Dp, j, g_colsum.p, S);
+                hipLaunchKernelGGL((k_lz_update<T>), dim3(gr), dim3(BLOCK), shcol, st, K, Dp, j, g_tm.p, blk(j), j > 1 ? blk(j - 1) : blk(j), blk(j + 1), S, part.p);
+                hipLaunchKernelGGL(k_colreduce, dim3((Dp + 15) / 16), dim3(BLOCK), 0, st, gr, Dp, part.p, g_colsum.p);
+                hipLaunchKernelGGL(k_lz_beta, dim3(1), dim3(64), 0, st, Dp, j, eps, g_colsum.p, S);
+            }
+            MMW_HIP(hipGetLastError());
+            const int m = j - 1;
+            MMW_HIP(hipMemcpyAsync(ha.data(), S.alpha, (size_t)(m + 1) * Dp * sizeof(double), hipMemcpyDeviceToHost, st));
+            MMW_HIP(hipMemcpyAsync(hb.data(), S.beta, (size_t)(m + 1) * Dp * sizeof(double), hipMemcpyDeviceToHost, st));
+            MMW_HIP(hipStreamSynchronize(st));
+            a.assign(m, 0.0);
+            b.assign(m, 0.0);
+            int mm = m;
+            for (int i = 1; i <= m; ++i) {
+                a[i - 1] = ha[(size_t)i * Dp];
+                b[i - 1] = hb[(size_t)i * Dp];  // beta_i couples i and i+1
+                if (i < m && b[i - 1] == 0.0) {  // invariant subspace found
+                    mm = i;
+                    break;
+                }
+            }
+            double lastc = 0.0;
+            theta = tridiag_min_eig(a, b, mm, &lastc);
+            double scale = 0.0;
+            for (int i = 0; i < mm; ++i) scale = std::max(scale, std::fabs(a[i]) + (i < mm - 1 ? std::fabs(b[i]) : 0.0));
+            const double resid = std::fabs(b[mm - 1] * lastc);
+            if (mm < m || resid <= tol * std::max(scale, 1e-300) || m >= K) break;
+        }
+        *lam = theta;
+        return MMW_OK;
+    }
+
+    int factor(const int* indptr, const int* col, const T* xavg, int nit, int32_t rank, double* out, uint64_t seed) {
+        return fac.run(indptr, col, xavg, 1.0 / (double)nit, rank, seed, out);
+    }
+    int read_factor(double* out, int64_t n) {
+        if ((int64_t)fac.last.size() != n || n == 0) return fail(MMW_ERR_STATE, "mmw_read_f64(FACTOR): no factor of that size has been computed");
+        memcpy(out, fac.last.data(), fac.last.size() * sizeof(double));
+        return MMW_OK;
+    }
 
     int round(int32_t Z, int32_t Dp, const double* gX_h, int32_t nb, const double* randv_h, int32_t* z_out, int32_t* rem_out) {
         if (Z < 1 || Dp < 1 || nb < 1) return fail(MMW_ERR_ARG, "mmw_round: Z, D' and nbatch must be positive");
