@@ -58,6 +58,7 @@ enum mmw_field {
     MMW_F_PHASE_US = 12,  /* [4*iters] per-iteration device us: dual, loss, expm, total (mmw.py:141,169,196,199) */
     MMW_F_EXPM_INFO = 13, /* [4]      last plan: one-norm bound, Krylov order m, substeps, shift mu */
     MMW_F_FACTOR = 14,    /* [K*rank] last factor of the averaged X (mmw.py:213-216)    */
+    MMW_F_BLOCKING = 16,  /* [4]      locality blocking: in use (0/1), row blocks, nnz per staged row (reuse), staged rows */
     MMW_F_KERNEL_US = 15  /* [2*9]    per kernel class {total device us, launches} since mmw_set_profile(1):
                              spmm, sddmm, dual, loss, krylov vector ops, sketch, projection, greedy, factor */
 };
@@ -104,6 +105,10 @@ int mmw_set_timing(mmw_solver* s, int enabled);
 
 /* 1: bracket every kernel class with HIP events on the solver's stream (fills MMW_F_KERNEL_US); clears the sums */
 int mmw_set_profile(mmw_solver* s, int enabled);
+
+/* micro-benchmark of the dominant kernel on the handle's pattern and current L values: `reps` launches of the
+ * CSR SpMM (blocked = 1: LDS-staged locality-blocked kernel, 0: generic gather kernel); mean device us per launch */
+int mmw_bench_spmm(mmw_solver* s, int blocked, int reps, double* avg_us);
 
 /* back to the initial point of mmw.py:62-73 for a fresh run of `nit` iterations on the same (state, Z) */
 int mmw_reset(mmw_solver* s, int32_t nit);

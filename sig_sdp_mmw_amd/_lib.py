@@ -16,12 +16,12 @@ EXPM_LANCZOS, EXPM_TAYLOR = 0, 1
 
 # enum mmw_field / mmw_ifield
 F_Y, F_E_ACCU, F_E_THIS, F_LVAL, F_XVAL, F_XAVG, F_YAVG, F_XHALF, F_SKETCH = range(9)
-F_S_SUM, F_NORM_H, F_ST_DATA, F_PHASE_US, F_EXPM_INFO, F_FACTOR, F_KERNEL_US = range(9, 16)
+F_S_SUM, F_NORM_H, F_ST_DATA, F_PHASE_US, F_EXPM_INFO, F_FACTOR, F_KERNEL_US, F_BLOCKING = range(9, 17)
 KERNEL_CLASSES = ["spmm", "sddmm", "dual", "loss", "krylov_vec", "sketch", "project", "greedy", "factor"]
 I_L_INDPTR, I_L_INDICES, I_ST_INDPTR, I_ST_INDICES, I_GAIN_X, I_GAIN_Y, I_ASSO_X, I_ASSO_Y, I_DIAG_POS, I_ASSO_POS = range(10)
 
 EXPORTS = ["mmw_last_error", "mmw_version", "mmw_device_count", "mmw_create", "mmw_destroy", "mmw_sizes", "mmw_set_expm",
-           "mmw_set_timing", "mmw_set_profile", "mmw_reset", "mmw_iterate", "mmw_sync", "mmw_read_f64", "mmw_read_i32", "mmw_gap",
+           "mmw_set_timing", "mmw_set_profile", "mmw_bench_spmm", "mmw_reset", "mmw_iterate", "mmw_sync", "mmw_read_f64", "mmw_read_i32", "mmw_gap",
            "mmw_factor", "mmw_expm_apply", "mmw_round"]
 
 
@@ -54,6 +54,7 @@ def lib():
     L.mmw_set_expm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double]
     L.mmw_set_timing.argtypes = [C.c_void_p, C.c_int]
     L.mmw_set_profile.argtypes = [C.c_void_p, C.c_int]
+    L.mmw_bench_spmm.argtypes = [C.c_void_p, C.c_int, C.c_int, p_f64]
     L.mmw_reset.argtypes = [C.c_void_p, C.c_int32]
     L.mmw_iterate.argtypes = [C.c_void_p, C.c_int32, p_f64, C.c_uint64]
     L.mmw_sync.argtypes = [C.c_void_p]
@@ -162,6 +163,11 @@ class Solver:
         v = self.read(F_KERNEL_US, 2 * len(KERNEL_CLASSES))
         return {k: (float(v[2 * i]), int(v[2 * i + 1])) for i, k in enumerate(KERNEL_CLASSES)}
 
+    def bench_spmm(self, blocked=True, reps=20):
+        us = C.c_double(0.0)
+        check(lib().mmw_bench_spmm(self._h, 1 if blocked else 0, int(reps), C.byref(us)))
+        return us.value
+
     def reset(self, nit):
         check(lib().mmw_reset(self._h, int(nit)))
         self._timed = 0
@@ -187,7 +193,7 @@ class Solver:
         if n is None:
             if which in (F_XHALF, F_SKETCH):
                 n = self.K * self.D
-            elif which == F_EXPM_INFO:
+            elif which in (F_EXPM_INFO, F_BLOCKING):
                 n = 4
             elif which == F_PHASE_US:
                 n = 4 * self._timed_iters()

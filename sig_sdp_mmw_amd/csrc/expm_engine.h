@@ -46,6 +46,28 @@ inline int spmm_launch(hipStream_t st, int K, const BlockLayout& lay, int nblk, 
     return MMW_OK;
 }
 
+// one launch of the LDS-staged blocked SpMM (values in blocked order)
+template <typename T, int MODE>
+inline int spmm_blk_launch(hipStream_t st, const BlkDev& B, int Dpad, const T* val_blk, const T* in, T* out, T* F, const T* X2,
+                           double c1, double c2, double c3, double* partial) {
+    constexpr int CT = BLK_TILE_BYTES / (int)sizeof(T);
+    const int ntiles = (Dpad + CT - 1) / CT;
+    int tpw = (int)((double)B.nb * ntiles / (3.0 * 256.0) + 0.5);  // ~3 workgroups per CU over the launch
+    if (getenv("MMW_TPW")) tpw = atoi(getenv("MMW_TPW"));
+    tpw = tpw < 1 ? 1 : (tpw > ntiles ? ntiles : tpw);
+    const int total = B.nb * ((ntiles + tpw - 1) / tpw);
+    const int per = (total + 7) / 8;
+    const size_t sh = (size_t)BLK_UNION_ROWS * BLK_TILE_BYTES + BLK_META_LDS + (size_t)BLK_WAVES * CT * sizeof(double);
+    static bool attr_set = false;  // per (T, MODE) instantiation
+    if (!attr_set) {
+        MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_blk<T, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_spmm_blk<T, MODE>), dim3(per * 8), dim3(BLK_THREADS), sh, st, B, Dpad, ntiles, tpw, val_blk, in, out, F, X2, c1, c2, c3, partial, getenv("MMW_DBG") ? atoi(getenv("MMW_DBG")) : 0);
+    MMW_HIP(hipGetLastError());
+    return MMW_OK;
+}
+
 template <typename T> struct ExpmEngine {
     hipStream_t st = nullptr;
     int K = 0;
@@ -64,6 +86,10 @@ template <typename T> struct ExpmEngine {
     ExpmPlan last{};
     size_t bs = 0;      // elements per block
     KernelTimers* kt = nullptr;  // optional
+    bool use_blk = false;        // LDS-staged blocked SpMM (blocking.h) instead of the generic gather kernel
+    BlkDev blk{};
+    const T* val_blk = nullptr;
+    int npart = 1;               // partial slabs one SpMM launch writes
     int kbegin(int slot) { return kt ? kt->begin(slot) : MMW_OK; }
     int kend() { return kt ? kt->end() : MMW_OK; }
 
@@ -83,6 +109,7 @@ template <typename T> struct ExpmEngine {
         MMW_TRY(U.alloc(bs * (size_t)(MAX_ORDER + 1)));
         MMW_TRY(Tm.alloc(bs));
         MMW_TRY(partial.alloc((size_t)MAX_PART * lay.Dpad));
+        npart = nblk;
         MMW_TRY(colsum.alloc(lay.Dpad));
         MMW_TRY(scal.alloc((size_t)4 * (MAX_ORDER + 2) * lay.Dpad));
         MMW_TRY(rho_part.alloc(MAX_PART));
@@ -106,8 +133,19 @@ template <typename T> struct ExpmEngine {
 
     template <int MODE> int launch_spmm(const T* in, T* out, T* F, double ascale, double shift, double inv_k) {
         MMW_TRY(kbegin(KT_SPMM));
-        MMW_TRY((spmm_launch<T, MODE>(st, K, lay, nblk, indptr, col, val, in, out, F, nullptr, ascale, shift, inv_k, partial.p)));
+        if (use_blk)
+            MMW_TRY((spmm_blk_launch<T, MODE>(st, blk, lay.Dpad, val_blk, in, out, F, nullptr, ascale, shift, inv_k, partial.p)));
+        else
+            MMW_TRY((spmm_launch<T, MODE>(st, K, lay, nblk, indptr, col, val, in, out, F, nullptr, ascale, shift, inv_k, partial.p)));
         return kend();
+    }
+    int enable_blocking(const BlkDev& b, const T* values_blocked) {
+        blk = b;
+        val_blk = values_blocked;
+        use_blk = true;
+        npart = b.nb;
+        if ((size_t)b.nb > (size_t)MAX_PART) MMW_TRY(partial.alloc((size_t)b.nb * lay.Dpad));
+        return MMW_OK;
     }
     int colreduce(int nb) {
         hipLaunchKernelGGL(k_colreduce, dim3((lay.Dpad + 15) / 16), dim3(BLOCK), 0, st, nb, lay.Dpad, partial.p, colsum.p);
@@ -153,7 +191,7 @@ template <typename T> struct ExpmEngine {
                 hipLaunchKernelGGL(k_lz_init, dim3(gcol), dim3(64), 0, st, Dpad, colsum.p, S);
                 for (int j = 1; j <= m; ++j) {
                     MMW_TRY((launch_spmm<SPMM_LANCZOS>(block(j - 1), Tm.p, nullptr, ascale, 0.0, 1.0)));
-                    MMW_TRY(colreduce(nblk));
+                    MMW_TRY(colreduce(npart));
                     hipLaunchKernelGGL(k_lz_alpha, dim3(gcol), dim3(64), 0, st, Dpad, j, colsum.p, S);
                     if (j < m) {
                         hipLaunchKernelGGL((k_lz_update<T>), dim3(gr), dim3(BLOCK), shcol, st, K, Dpad, j, Tm.p, block(j - 1),

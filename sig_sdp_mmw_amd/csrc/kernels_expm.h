@@ -160,6 +160,202 @@ __global__ __launch_bounds__(BLOCK) void k_spmm(int K, BlockLayout lay, const in
     }
 }
 
+// ---- LDS-staged SpMM over locality blocks (blocking.h) ------------------------------------------
+// One workgroup (8 waves) per (row block, 256-byte column tile):
+//   phase 1  gathers the block's union of dense rows into LDS (each row segment one coalesced 256-B read,
+//            all of a thread's gathers in flight at once) and copies the block's (local index, value)
+//            entries next to it;
+//   phase 2  serves every nonzero of the row block from LDS: a 16-lane group owns one nonzero, so one
+//            ds_read_b128 wave-instruction reads four full 256-B rows, each service group touching all 64
+//            banks once (conflict-free by construction).
+// Same fused epilogues as k_spmm.  Values arrive in blocked, chunk-padded order (val_blk).
+struct BlkDev {
+    int nb;
+    const int* rowptr;        // [nb+1] positions into `order`
+    const int* order;         // position -> original row
+    const int* un_ptr;        // [nb+1]
+    const int* un_cols;       // original column ids
+    const int* bptr;          // [K+1] blocked entry ranges by position (multiples of 16)
+    const unsigned short* lidx;
+    const unsigned short* self_li;  // [K] by position: local index of the row itself (its diagonal entry)
+};
+constexpr int BLK_THREADS = 1024;
+constexpr int BLK_WAVES = BLK_THREADS / WAVE;
+constexpr int BLK_TILE_BYTES = 256;
+constexpr int BLK_UNION_ROWS = 448;
+constexpr int BLK_META_LDS = 40960;
+template <typename T> struct BlkMeta {  // one staged entry
+    unsigned int li;
+    T v;
+};
+// the 4 consecutive staged entries of one lane group, as wide LDS reads
+__device__ __forceinline__ void load_meta4(const BlkMeta<float>* p, unsigned (&li)[4], float (&v)[4]) {
+    const uint4 a = reinterpret_cast<const uint4*>(p)[0], b = reinterpret_cast<const uint4*>(p)[1];
+    li[0] = a.x; v[0] = __uint_as_float(a.y); li[1] = a.z; v[1] = __uint_as_float(a.w);
+    li[2] = b.x; v[2] = __uint_as_float(b.y); li[3] = b.z; v[3] = __uint_as_float(b.w);
+}
+__device__ __forceinline__ void load_meta4(const BlkMeta<double>* p, unsigned (&li)[4], double (&v)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint4 a = reinterpret_cast<const uint4*>(p)[u];
+        li[u] = a.x;
+        v[u] = __longlong_as_double(((long long)a.w << 32) | (long long)a.z);
+    }
+}
+template <typename T> constexpr int blk_max_entries() { return BLK_META_LDS / (int)sizeof(BlkMeta<T>); }
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, int ntiles, int tpw, const T* __restrict__ val_blk,
+                                                          const T* __restrict__ U, T* __restrict__ Out, T* __restrict__ F,
+                                                          const T* __restrict__ X2, double ascale, double shift, double inv_k,
+                                                          double* __restrict__ partial, int dbg) {
+    constexpr int VEC = V16<T>::N;
+    constexpr int CT = BLK_TILE_BYTES / (int)sizeof(T);  // columns per tile
+    constexpr int RPP = BLK_THREADS / 16;                // union rows gathered per pass
+    constexpr int NG = BLK_UNION_ROWS / RPP;             // gathers per thread
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* tile = reinterpret_cast<T*>(smem_raw);                                                        // [BLK_UNION_ROWS][CT]
+    BlkMeta<T>* meta = reinterpret_cast<BlkMeta<T>*>(smem_raw + (size_t)BLK_UNION_ROWS * BLK_TILE_BYTES);  // [entries]
+    double* shdot = reinterpret_cast<double*>(smem_raw + (size_t)BLK_UNION_ROWS * BLK_TILE_BYTES + BLK_META_LDS);  // [BLK_WAVES][CT]
+    // XCD-aware id: consecutive ids of one XCD walk consecutive row blocks of one tile group
+    const int ngroups = (ntiles + tpw - 1) / tpw;
+    const int total = B.nb * ngroups;
+    const int per = (total + 7) / 8;
+    const int id = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (id >= total) return;
+    const int tg = id / B.nb, rb = id - tg * B.nb;
+    const int t0 = tg * tpw, t1 = min(ntiles, t0 + tpw);
+    const int l16 = threadIdx.x & 15;
+    const int q0 = B.rowptr[rb], q1 = B.rowptr[rb + 1];
+    const int m0 = B.bptr[q0], nmeta = B.bptr[q1] - m0;
+    const int un0 = B.un_ptr[rb], nun = B.un_ptr[rb + 1] - un0;
+    const int u0 = threadIdx.x >> 4;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int g = lane >> 4;  // lane group = one nonzero per LDS read
+    // this thread's share of the union (same rows for every tile)
+    size_t gbase[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const int u = u0 + j * RPP;
+        gbase[j] = u < nun ? (size_t)B.un_cols[un0 + u] * Dpad : (size_t)0;
+    }
+    T x[NG][VEC];
+    auto gather = [&](int t) {
+        const int c = t * CT + l16 * VEC;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) x[j][v] = T(0);
+            if (u0 + j * RPP < nun && c < Dpad && !(dbg & 1)) load16(U + gbase[j] + c, x[j]);
+        }
+    };
+    auto deposit = [&]() {
+#pragma unroll
+        for (int j = 0; j < NG; ++j)
+            if (u0 + j * RPP < nun) store16(tile + (size_t)(u0 + j * RPP) * CT + l16 * VEC, x[j]);
+    };
+    gather(t0);
+    for (int i = threadIdx.x; i < nmeta; i += BLK_THREADS) {  // the block's entries, once for all its tiles
+        BlkMeta<T> e;
+        e.li = (unsigned)B.lidx[m0 + i] * BLK_TILE_BYTES;  // byte offset of the staged row
+        e.v = val_blk[m0 + i];
+        meta[i] = e;
+    }
+    deposit();
+    __syncthreads();
+    for (int t = t0; t < t1; ++t) {
+        if (t + 1 < t1) gather(t + 1);  // next tile's rows fly while this tile is consumed from LDS
+        const int col0 = t * CT;
+        const bool colok = col0 + l16 * VEC < Dpad;
+        double dot[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) dot[v] = 0.0;
+        for (int q = q0 + wib; q < q1; q += BLK_WAVES) {
+            T acc[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] = T(0);
+            // wave-uniform row extent -> scalar loop control, no divergence in the hot loop
+            const int beg = __builtin_amdgcn_readfirstlane(B.bptr[q]) - m0;
+            const int nch = (dbg & 2) ? 0 : (__builtin_amdgcn_readfirstlane(B.bptr[q + 1]) - m0 - beg) >> 4;
+            const BlkMeta<T>* mp = meta + beg + 4 * g;
+            const char* tbase = reinterpret_cast<const char*>(tile) + l16 * 16;
+            unsigned li[4];
+            T vv[4];
+            if (nch > 0) load_meta4(mp, li, vv);
+            for (int c = 0; c < nch; ++c) {
+                T xx[4][VEC];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) load16(reinterpret_cast<const T*>(tbase + li[u]), xx[u]);
+                T cv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) cv[u] = vv[u];
+                if (c + 1 < nch) load_meta4(mp + 16 * (c + 1), li, vv);  // next chunk's entries while this one's rows arrive
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[v] += cv[u] * xx[u][v];
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                acc[v] += __shfl_xor(acc[v], 16, WAVE);
+                acc[v] += __shfl_xor(acc[v], 32, WAVE);
+            }
+            if (g == 0 && colok) {
+                const int row = B.order[q];
+                const size_t off = (size_t)row * Dpad + col0 + l16 * VEC;
+                T o[VEC];
+                if (MODE == SPMM_PLAIN) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) o[v] = (T)(ascale * (double)acc[v]);
+                } else if (MODE == SPMM_LANCZOS) {
+                    T u[VEC];
+                    load16(tile + (size_t)B.self_li[q] * CT + l16 * VEC, u);  // U[row] is in the staged union (diagonal entry)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        o[v] = (T)(ascale * (double)acc[v]);
+                        dot[v] += (double)u[v] * (double)o[v];
+                    }
+                } else if (MODE == SPMM_AXPBY) {
+                    T f[VEC], x2[VEC];
+                    load16(F + off, f);
+                    load16(X2 + off, x2);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) o[v] = (T)(ascale * (double)acc[v] + shift * (double)f[v] + inv_k * (double)x2[v]);
+                } else {
+                    T u[VEC], f[VEC];
+                    load16(tile + (size_t)B.self_li[q] * CT + l16 * VEC, u);
+                    load16(F + off, f);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        o[v] = (T)((ascale * (double)acc[v] - shift * (double)u[v]) * inv_k);
+                        f[v] += o[v];
+                    }
+                    store16(F + off, f);
+                }
+                store16(Out + off, o);
+            }
+        }
+        if (MODE == SPMM_LANCZOS) {
+            if (g == 0)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) shdot[wib * CT + l16 * VEC + v] = dot[v];
+        }
+        __syncthreads();  // every wave is done with this tile (and shdot is complete)
+        if (MODE == SPMM_LANCZOS) {
+            for (int c = threadIdx.x; c < CT; c += BLK_THREADS)
+                if (col0 + c < Dpad) {
+                    double s = 0.0;
+                    for (int w = 0; w < BLK_WAVES; ++w) s += shdot[w * CT + c];
+                    partial[(size_t)rb * Dpad + col0 + c] = s;
+                }
+        }
+        if (t + 1 < t1) {
+            deposit();
+            __syncthreads();
+        }
+    }
+}
+
 // Column sums of squares of a block: partial[block][col] = sum over the block's rows of X^2.
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_colsq(int K, int Dpad, const T* __restrict__ X, double* __restrict__ partial) {

@@ -6,6 +6,7 @@
 // Reductions are wavefront shuffles + fixed-order per-block slabs (bitwise reproducible, no atomics).
 #pragma once
 #include "device_utils.h"
+#include "kernels_expm.h"
 
 namespace mmw {
 
@@ -145,7 +146,8 @@ __global__ __launch_bounds__(BLOCK) void k_softmax_b(int C, T* __restrict__ Y, T
 // ---- LOSS: lval -= eta * (LD + LF + LH) on the pattern; per-block partial of the diagonal sum ------
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_loss(PatternDev<T> P, const T* __restrict__ Y, const double* __restrict__ scal,
-                                                T* __restrict__ lval, double eta, double* __restrict__ trace_part) {
+                                                T* __restrict__ lval, double eta, double* __restrict__ trace_part,
+                                                const int* __restrict__ bpos, T* __restrict__ lval_blk) {
     __shared__ double sh[WAVES_PER_BLOCK];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int K = P.K, Z = P.Z, baseF = K, baseH = K + P.E_asso;
@@ -170,6 +172,7 @@ __global__ __launch_bounds__(BLOCK) void k_loss(PatternDev<T> P, const T* __rest
             }
             const T nv = (T)((double)lval[e] - eta * add);
             lval[e] = nv;
+            if (bpos) lval_blk[bpos[e]] = nv;  // the same value in the LDS-staged kernel's traversal order
             if (c == row) tr += (double)nv;
         }
     }
@@ -258,6 +261,135 @@ __global__ __launch_bounds__(BLOCK) void k_sddmm(PatternDev<T> P, int Dpad, int 
                 }
             }
         }
+    }
+}
+
+// ---- LDS-staged SDDMM over locality blocks (blocking.h) -------------------------------------------
+// One workgroup per row block.  Per 256-byte column tile the block's union of X_half rows is staged in
+// LDS exactly like k_spmm_blk does; every thread owns up to SD_ROUNDS upper-triangular entries (a,b) of
+// the block and accumulates <y_a, y_b> over the tile in registers, walking the 16 column chunks in a
+// lane-skewed order ((s + lane) mod 16) so the 16 lanes of an LDS service group touch 16 different
+// chunks = all 64 banks (conflict-free whatever rows they read).  No cross-lane reduction at all.
+struct SdDev {
+    const int* ptr;               // [nb+1]
+    const unsigned short* la;
+    const unsigned short* lb;
+    const int* epos;
+};
+constexpr int SD_ROUNDS = 3;
+template <typename T>
+__global__ __launch_bounds__(BLK_THREADS) void k_sddmm_blk(BlkDev B, SdDev S, PatternDev<T> P, int Dpad, int ntiles,
+                                                           const T* __restrict__ Yb, const T* __restrict__ d,
+                                                           const double* __restrict__ tr_part, int ntr, T* __restrict__ xval,
+                                                           T* __restrict__ xavg, int accumulate) {
+    constexpr int VEC = V16<T>::N;
+    constexpr int CT = BLK_TILE_BYTES / (int)sizeof(T);
+    constexpr int RPP = BLK_THREADS / 16;
+    constexpr int NG = BLK_UNION_ROWS / RPP;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* tile = reinterpret_cast<T*>(smem_raw);
+    __shared__ double sh[BLK_WAVES];
+    double tsum = 0.0;
+    for (int i = threadIdx.x; i < ntr; i += BLK_THREADS) tsum += tr_part[i];
+    tsum = block_sum(tsum, sh);
+    const double tr = tsum / (double)P.K;
+    const int per = (B.nb + 7) / 8;
+    const int rb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (rb >= B.nb) return;
+    const int l16 = threadIdx.x & 15;
+    const int u0 = threadIdx.x >> 4;
+    const int un0 = B.un_ptr[rb], nun = B.un_ptr[rb + 1] - un0;
+    size_t gbase[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const int u = u0 + j * RPP;
+        gbase[j] = u < nun ? (size_t)B.un_cols[un0 + u] * Dpad : (size_t)0;
+    }
+    T x[NG][VEC];
+    auto gather = [&](int t) {
+        const int c = t * CT + l16 * VEC;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) x[j][v] = T(0);
+            if (u0 + j * RPP < nun && c < Dpad) load16(Yb + gbase[j] + c, x[j]);
+        }
+    };
+    auto deposit = [&]() {
+#pragma unroll
+        for (int j = 0; j < NG; ++j)
+            if (u0 + j * RPP < nun) store16(tile + (size_t)(u0 + j * RPP) * CT + l16 * VEC, x[j]);
+    };
+    gather(0);
+    // this thread's entries
+    const int e0 = S.ptr[rb], ne = S.ptr[rb + 1] - e0;
+    unsigned offa[SD_ROUNDS], offb[SD_ROUNDS];
+    int ep[SD_ROUNDS];
+    double acc[SD_ROUNDS];
+#pragma unroll
+    for (int k = 0; k < SD_ROUNDS; ++k) {
+        const int i = threadIdx.x + k * BLK_THREADS;
+        acc[k] = 0.0;
+        ep[k] = -1;
+        offa[k] = offb[k] = 0;
+        if (i < ne) {
+            offa[k] = (unsigned)S.la[e0 + i] * BLK_TILE_BYTES;
+            offb[k] = (unsigned)S.lb[e0 + i] * BLK_TILE_BYTES;
+            ep[k] = S.epos[e0 + i];
+        }
+    }
+    deposit();
+    __syncthreads();
+    const char* tb = reinterpret_cast<const char*>(tile);
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) gather(t + 1);
+#pragma unroll
+        for (int k = 0; k < SD_ROUNDS; ++k) {
+            if (ep[k] >= 0) {
+                T s[VEC];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) s[v] = T(0);
+#pragma unroll
+                for (int st = 0; st < 16; ++st) {
+                    const int ch = ((st + l16) & 15) * 16;
+                    T xa[VEC], xb[VEC];
+                    load16(reinterpret_cast<const T*>(tb + offa[k] + ch), xa);
+                    load16(reinterpret_cast<const T*>(tb + offb[k] + ch), xb);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) s[v] += xa[v] * xb[v];
+                }
+                double ss = 0.0;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) ss += (double)s[v];
+                acc[k] += ss;
+            }
+        }
+        __syncthreads();
+        if (t + 1 < ntiles) {
+            deposit();
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < SD_ROUNDS; ++k)
+        if (ep[k] >= 0) {
+            const T xv = (T)(acc[k] / tr);
+            const int e = ep[k], me = P.mirror[e];
+            xval[e] = xv;
+            xval[me] = xv;
+            if (accumulate) {
+                xavg[e] += xv;
+                xavg[me] += xv;
+            }
+        }
+    // diagonal of the block's rows
+    const int q0 = B.rowptr[rb], q1 = B.rowptr[rb + 1];
+    for (int q = q0 + threadIdx.x; q < q1; q += BLK_THREADS) {
+        const int row = B.order[q];
+        const int dp = P.diag_pos[row];
+        const T xd = (T)((double)d[row] / tr);
+        xval[dp] = xd;
+        if (accumulate) xavg[dp] += xd;
     }
 }
 

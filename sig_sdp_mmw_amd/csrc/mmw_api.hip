@@ -3,6 +3,7 @@
 #include <cstring>
 #include <memory>
 
+#include "blocking.h"
 #include "expm_engine.h"
 #include "kernels_loop.h"
 #include "pattern.h"
@@ -17,6 +18,7 @@ struct mmw_solver {
     virtual int set_expm(int method, int max_order, double tol) = 0;
     virtual int set_timing(int enabled) = 0;
     virtual int set_profile(int enabled) = 0;
+    virtual int bench_spmm(int blocked, int reps, double* avg_us) = 0;
     virtual int reset(int32_t nit) = 0;
     virtual int iterate(int32_t n, const double* randv, uint64_t seed) = 0;
     virtual int sync() = 0;
@@ -44,6 +46,14 @@ template <typename T> struct Solver final : mmw_solver {
     // iterate state
     DevBuf<T> lval, xval, xavg, Y, yavg, e_accu, e_this, rsum, Xh, drow;
     DevBuf<double> max_part, sum_part, scal, trace_part, tr_part, stage64, out64;
+    // locality blocking (blocking.h)
+    HostBlocking HB;
+    DevBuf<int> b_rowptr, b_order, b_unptr, b_uncols, b_bptr, b_bpos, b_bepos;
+    DevBuf<unsigned short> b_lidx, b_selfli, b_sdla, b_sdlb;
+    DevBuf<int> b_sdptr, b_sdepos;
+    bool sddmm_blk = false;
+    DevBuf<T> lval_blk;
+    int blocking_mode = 1;  // 1: use when profitable, 0: never
     ExpmEngine<T> eng;
     Extras<T> extras;
     KernelTimers kt;
@@ -108,12 +118,40 @@ template <typename T> struct Solver final : mmw_solver {
         eng.max_order = 12;
         eng.tol = sizeof(T) == 4 ? 1e-6 : 1e-9;
         MMW_TRY(Xh.alloc(eng.bs));
+        MMW_TRY(setup_blocking());
         size_t big = std::max(std::max(nnz, C), eng.bs);
         MMW_TRY(out64.alloc(big));
         MMW_TRY(stage64.alloc((size_t)K * D));
         MMW_HIP(hipStreamSynchronize(st));
         MMW_TRY(extras.init(this->st, &H, K, &kt));
         return reset(nit);
+    }
+
+    BlkDev blkdev() const {
+        BlkDev B;
+        B.nb = HB.nb(); B.rowptr = b_rowptr.p; B.order = b_order.p; B.un_ptr = b_unptr.p; B.un_cols = b_uncols.p;
+        B.bptr = b_bptr.p; B.lidx = b_lidx.p; B.self_li = b_selfli.p;
+        return B;
+    }
+    int setup_blocking() {
+        const char* env = getenv("MMW_BLOCKING");
+        if (env && env[0] == '0') blocking_mode = 0;
+        if (!blocking_mode) return MMW_OK;
+        build_blocking(HB, K, H.l_indptr, H.l_indices, blk_max_entries<T>());
+        if (!HB.usable) return MMW_OK;
+        MMW_TRY(b_rowptr.upload(HB.blk_rowptr, st)); MMW_TRY(b_order.upload(HB.order, st)); MMW_TRY(b_unptr.upload(HB.un_ptr, st));
+        MMW_TRY(b_uncols.upload(HB.un_cols, st)); MMW_TRY(b_bptr.upload(HB.bptr, st)); MMW_TRY(b_bpos.upload(HB.bpos, st));
+        MMW_TRY(b_bepos.upload(HB.bepos, st)); MMW_TRY(b_lidx.upload(HB.lidx, st)); MMW_TRY(b_selfli.upload(HB.self_li, st));
+        MMW_TRY(lval_blk.alloc((size_t)HB.nent));
+        if (HB.sd_max <= SD_ROUNDS * BLK_THREADS) {
+            MMW_TRY(b_sdptr.upload(HB.sd_ptr, st)); MMW_TRY(b_sdla.upload(HB.sd_la, st)); MMW_TRY(b_sdlb.upload(HB.sd_lb, st));
+            MMW_TRY(b_sdepos.upload(HB.sd_epos, st));
+            const size_t shb = (size_t)BLK_UNION_ROWS * BLK_TILE_BYTES;
+            MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sddmm_blk<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
+            sddmm_blk = true;
+        }
+        MMW_HIP(hipStreamSynchronize(st));
+        return eng.enable_blocking(blkdev(), lval_blk.p);
     }
 
     int sizes(int64_t out[10]) override {
@@ -132,6 +170,31 @@ template <typename T> struct Solver final : mmw_solver {
         timing = enabled != 0;
         return MMW_OK;
     }
+    // SpMM micro-benchmark on the current L values: Tm = 0.5 * L * start_block, `reps` launches
+    int bench_spmm(int blocked, int reps, double* avg_us) override {
+        if (host_only) return fail(MMW_ERR_STATE, "host-only handle");
+        MMW_HIP(hipSetDevice(device));
+        if (blocked && !HB.usable) return fail(MMW_ERR_STATE, "no locality blocking for this pattern");
+        MMW_TRY(sync());
+        hipLaunchKernelGGL((k_sketch_rng<T>), dim3(grid_rows(K)), dim3(BLOCK), 0, st, K, D, eng.lay.Dpad, 99ull, 0u, eng.start_block());
+        const bool keep = eng.use_blk;
+        eng.use_blk = blocked != 0;
+        hipEvent_t e0, e1;
+        MMW_HIP(hipEventCreate(&e0));
+        MMW_HIP(hipEventCreate(&e1));
+        int rc = eng.template launch_spmm<SPMM_PLAIN>(eng.start_block(), eng.Tm.p, nullptr, 0.5, 0.0, 1.0);  // warm
+        MMW_HIP(hipEventRecord(e0, st));
+        for (int r = 0; r < reps && rc == MMW_OK; ++r) rc = eng.template launch_spmm<SPMM_PLAIN>(eng.start_block(), eng.Tm.p, nullptr, 0.5, 0.0, 1.0);
+        MMW_HIP(hipEventRecord(e1, st));
+        MMW_HIP(hipStreamSynchronize(st));
+        eng.use_blk = keep;
+        float ms = 0;
+        MMW_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (avg_us) *avg_us = ms * 1e3 / (reps > 0 ? reps : 1);
+        return rc;
+    }
     int set_profile(int enabled) override {
         if (host_only) return fail(MMW_ERR_STATE, "host-only handle");
         MMW_TRY(sync());
@@ -148,6 +211,7 @@ template <typename T> struct Solver final : mmw_solver {
         iter = 0;
         const size_t nnz = (size_t)H.nnzL(), C = (size_t)H.C();
         MMW_HIP(hipMemsetAsync(lval.p, 0, nnz * sizeof(T), st));
+        if (lval_blk.p) MMW_HIP(hipMemsetAsync(lval_blk.p, 0, (size_t)HB.nent * sizeof(T), st));
         MMW_HIP(hipMemsetAsync(xval.p, 0, nnz * sizeof(T), st));
         MMW_HIP(hipMemsetAsync(xavg.p, 0, nnz * sizeof(T), st));
         MMW_HIP(hipMemsetAsync(e_accu.p, 0, C * sizeof(T), st));
@@ -209,7 +273,8 @@ template <typename T> struct Solver final : mmw_solver {
             MMW_TRY(record(1));
             // ---- LOSS
             MMW_TRY(kt.begin(KT_LOSS));
-            hipLaunchKernelGGL((k_loss<T>), dim3(gr), dim3(BLOCK), 0, st, P, Y.p, scal.p, lval.p, eta, trace_part.p);
+            hipLaunchKernelGGL((k_loss<T>), dim3(gr), dim3(BLOCK), 0, st, P, Y.p, scal.p, lval.p, eta, trace_part.p,
+                               (const int*)(eng.use_blk ? b_bpos.p : nullptr), lval_blk.p);
             MMW_TRY(kt.end());
             MMW_TRY(record(2));
             // ---- EXPM + X on the pattern
@@ -228,6 +293,15 @@ template <typename T> struct Solver final : mmw_solver {
             MMW_TRY(eng.apply(Xh.p, 0.5, trace_part.p, gr));
             MMW_TRY(kt.begin(KT_SDDMM));
             hipLaunchKernelGGL((k_rownorm2<T>), dim3(gr), dim3(BLOCK), 0, st, K, Dpad, Xh.p, drow.p, tr_part.p);
+            if (sddmm_blk && eng.use_blk) {
+                SdDev S;
+                S.ptr = b_sdptr.p; S.la = b_sdla.p; S.lb = b_sdlb.p; S.epos = b_sdepos.p;
+                constexpr int CT = BLK_TILE_BYTES / (int)sizeof(T);
+                const int ntiles = (Dpad + CT - 1) / CT;
+                const int per = (HB.nb() + 7) / 8;
+                hipLaunchKernelGGL((k_sddmm_blk<T>), dim3(per * 8), dim3(BLK_THREADS), (size_t)BLK_UNION_ROWS * BLK_TILE_BYTES, st, blkdev(), S, P, Dpad,
+                                   ntiles, Xh.p, drow.p, tr_part.p, gr, xval.p, xavg.p, acc);
+            } else
             switch (eng.lay.NCH) {
                 case 1: hipLaunchKernelGGL((k_sddmm<T, 1>), dim3(gr), dim3(BLOCK), 0, st, P, Dpad, eng.lay.LPR, eng.lay.G, Xh.p, drow.p, tr_part.p, gr, xval.p, xavg.p, acc); break;
                 case 2: hipLaunchKernelGGL((k_sddmm<T, 2>), dim3(gr), dim3(BLOCK), 0, st, P, Dpad, eng.lay.LPR, eng.lay.G, Xh.p, drow.p, tr_part.p, gr, xval.p, xavg.p, acc); break;
@@ -304,6 +378,11 @@ template <typename T> struct Solver final : mmw_solver {
             case MMW_F_EXPM_INFO: {
                 if (n != 4) return fail(MMW_ERR_ARG, "expm info has 4 entries");
                 out[0] = eng.last.rho; out[1] = eng.last.m; out[2] = eng.last.nsub; out[3] = eng.last.mu;
+                return MMW_OK;
+            }
+            case MMW_F_BLOCKING: {
+                if (n != 4) return fail(MMW_ERR_ARG, "blocking info has 4 entries");
+                out[0] = eng.use_blk ? 1.0 : 0.0; out[1] = HB.usable ? HB.nb() : 0; out[2] = HB.reuse; out[3] = (double)HB.un_cols.size();
                 return MMW_OK;
             }
             case MMW_F_FACTOR: return extras.read_factor(out, n);
@@ -467,6 +546,7 @@ int mmw_sizes(mmw_solver* s, int64_t out[10]) { MMW_NEED(s); return s->sizes(out
 int mmw_set_expm(mmw_solver* s, int method, int max_order, double tol) { MMW_NEED(s); return s->set_expm(method, max_order, tol); }
 int mmw_set_timing(mmw_solver* s, int enabled) { MMW_NEED(s); return s->set_timing(enabled); }
 int mmw_set_profile(mmw_solver* s, int enabled) { MMW_NEED(s); return s->set_profile(enabled); }
+int mmw_bench_spmm(mmw_solver* s, int blocked, int reps, double* avg_us) { MMW_NEED(s); return s->bench_spmm(blocked, reps, avg_us); }
 int mmw_reset(mmw_solver* s, int32_t nit) { MMW_NEED(s); return s->reset(nit); }
 int mmw_iterate(mmw_solver* s, int32_t n, const double* randv, uint64_t seed) { MMW_NEED(s); return s->iterate(n, randv, seed); }
 int mmw_sync(mmw_solver* s) { MMW_NEED(s); return s->sync(); }

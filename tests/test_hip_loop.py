@@ -160,3 +160,45 @@ def test_phase_timers_are_filled():
     t = s.read(_lib.F_PHASE_US).reshape(5, 4)
     assert np.all(t > 0) and np.all(t[:, 3] >= t[:, :3].max(axis=1))
     s.close()
+
+
+def test_blocked_and_generic_spmm_agree(run_case, monkeypatch):
+    """The LDS-staged locality-blocked SpMM and the generic gather SpMM are two traversals of the same sums."""
+    name, g = run_case
+    state = state_from(g)
+    Z, nit, eta = int(g["Z"]), int(g["nit"]), float(g["eta"])
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MMW_BLOCKING", mode)
+        for dtype in (_lib.F64, _lib.F32):
+            s = _lib.Solver(Z, state, nit, eta, dtype=dtype)
+            info = s.read(_lib.F_BLOCKING)
+            assert info[0] == (1.0 if mode == "1" else 0.0), (name, info)
+            s.set_expm(_lib.EXPM_LANCZOS, 16, 1e-13 if dtype == _lib.F64 else 1e-7)
+            s.iterate(nit, g["randv"][:nit])
+            outs[(mode, dtype)] = (s.read(_lib.F_XHALF), s.read(_lib.F_LVAL))
+            s.close()
+    for dtype, bar in ((_lib.F64, 1e-12), (_lib.F32, 2e-5)):
+        assert relerr(outs[("1", dtype)][0], outs[("0", dtype)][0]) < bar
+        assert relerr(outs[("1", dtype)][1], outs[("0", dtype)][1]) < bar
+
+
+@pytest.mark.parametrize("kind", ["journal", "er"])
+def test_blocking_on_mid_size_graphs(kind):
+    from sig_sdp_mmw_amd.graphs import er_contention_graph, journal_graph
+    state = journal_graph(14, 0.012, seed=2) if kind == "journal" else er_contention_graph(1500, 0.02, 3)
+    K = state[0].shape[0]
+    Z, nit = 30, 3
+    rng = np.random.default_rng(1)
+    sk = np.stack([orc.sketch_rows(rng.standard_normal((K, 2 * Z))) for _ in range(nit)])
+    o = orc.MMWOracle(nit=nit, eta=0.05)
+    o.run(Z, state, lambda i, K_, D_: sk[i], keep_trace=True, factor=False)
+    for dtype, bar in ((_lib.F64, 1e-9), (_lib.F32, 1e-5)):
+        s = _lib.Solver(Z, state, nit, 0.05, dtype=dtype)
+        s.set_expm(_lib.EXPM_LANCZOS, 16, 1e-12 if dtype == _lib.F64 else 1e-7)
+        info = s.read(_lib.F_BLOCKING)
+        if kind == "journal":
+            assert info[0] == 1.0 and info[2] > 3.0  # geometric graph: real reuse
+        s.iterate(nit, sk)
+        assert relerr(s.read(_lib.F_XHALF), o.trace["X_half"][-1]) < bar, (kind, dtype, info)
+        s.close()
