@@ -58,7 +58,8 @@ enum mmw_field {
     MMW_F_PHASE_US = 12,  /* [4*iters] per-iteration device us: dual, loss, expm, total (mmw.py:141,169,196,199) */
     MMW_F_EXPM_INFO = 13, /* [4]      last plan: one-norm bound, Krylov order m, substeps, shift mu */
     MMW_F_FACTOR = 14,    /* [K*rank] last factor of the averaged X (mmw.py:213-216)    */
-    MMW_F_BLOCKING = 16,  /* [4]      locality blocking: in use (0/1), row blocks, nnz per staged row (reuse), staged rows */
+    MMW_F_BLOCKING = 16,  /* [4]      locality blocking: in use (0/1), row blocks, nnz per staged row (reuse); [3] = batches replayed
+                             because the device-side Krylov order outgrew the launched stages */
     MMW_F_KERNEL_US = 15  /* [2*9]    per kernel class {total device us, launches} since mmw_set_profile(1):
                              spmm, sddmm, dual, loss, krylov vector ops, sketch, projection, greedy, factor */
 };

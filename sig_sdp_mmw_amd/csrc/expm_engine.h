@@ -34,13 +34,14 @@ inline int make_layout(int D, int vec, BlockLayout& lay, std::string& err) {
 // one launch of the CSR SpMM (any fused epilogue) for a block with layout `lay`
 template <typename T, int MODE>
 inline int spmm_launch(hipStream_t st, int K, const BlockLayout& lay, int nblk, const int* indptr, const int* col, const T* val,
-                       const T* in, T* out, T* F, const T* X2, double c1, double c2, double c3, double* partial) {
+                       const T* in, T* out, T* F, const T* X2, double c1, double c2, double c3, double* partial,
+                       const ExpmPlan* plan = nullptr, int step = 0) {
     const size_t sh = MODE == SPMM_LANCZOS ? (size_t)WAVES_PER_BLOCK * lay.Dpad * sizeof(double) : 0;
     switch (lay.NCH) {
-        case 1: hipLaunchKernelGGL((k_spmm<T, 1, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, X2, c1, c2, c3, partial); break;
-        case 2: hipLaunchKernelGGL((k_spmm<T, 2, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, X2, c1, c2, c3, partial); break;
-        case 3: hipLaunchKernelGGL((k_spmm<T, 3, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, X2, c1, c2, c3, partial); break;
-        default: hipLaunchKernelGGL((k_spmm<T, 4, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, X2, c1, c2, c3, partial); break;
+        case 1: hipLaunchKernelGGL((k_spmm<T, 1, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, X2, c1, c2, c3, partial, plan, step); break;
+        case 2: hipLaunchKernelGGL((k_spmm<T, 2, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, X2, c1, c2, c3, partial, plan, step); break;
+        case 3: hipLaunchKernelGGL((k_spmm<T, 3, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, X2, c1, c2, c3, partial, plan, step); break;
+        default: hipLaunchKernelGGL((k_spmm<T, 4, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, X2, c1, c2, c3, partial, plan, step); break;
     }
     MMW_HIP(hipGetLastError());
     return MMW_OK;
@@ -49,11 +50,10 @@ inline int spmm_launch(hipStream_t st, int K, const BlockLayout& lay, int nblk, 
 // one launch of the LDS-staged blocked SpMM (values in blocked order)
 template <typename T, int MODE>
 inline int spmm_blk_launch(hipStream_t st, const BlkDev& B, int Dpad, const T* val_blk, const T* in, T* out, T* F, const T* X2,
-                           double c1, double c2, double c3, double* partial) {
+                           double c1, double c2, double c3, double* partial, const ExpmPlan* plan = nullptr, int step = 0) {
     constexpr int CT = BLK_TILE_BYTES / (int)sizeof(T);
     const int ntiles = (Dpad + CT - 1) / CT;
     int tpw = (int)((double)B.nb * ntiles / (3.0 * 256.0) + 0.5);  // ~3 workgroups per CU over the launch
-    if (getenv("MMW_TPW")) tpw = atoi(getenv("MMW_TPW"));
     tpw = tpw < 1 ? 1 : (tpw > ntiles ? ntiles : tpw);
     const int total = B.nb * ((ntiles + tpw - 1) / tpw);
     const int per = (total + 7) / 8;
@@ -63,7 +63,7 @@ inline int spmm_blk_launch(hipStream_t st, const BlkDev& B, int Dpad, const T* v
         MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_blk<T, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_spmm_blk<T, MODE>), dim3(per * 8), dim3(BLK_THREADS), sh, st, B, Dpad, ntiles, tpw, val_blk, in, out, F, X2, c1, c2, c3, partial, getenv("MMW_DBG") ? atoi(getenv("MMW_DBG")) : 0);
+    hipLaunchKernelGGL((k_spmm_blk<T, MODE>), dim3(per * 8), dim3(BLK_THREADS), sh, st, B, Dpad, ntiles, tpw, val_blk, in, out, F, X2, c1, c2, c3, partial, plan, step);
     MMW_HIP(hipGetLastError());
     return MMW_OK;
 }
@@ -82,6 +82,7 @@ template <typename T> struct ExpmEngine {
     DevBuf<T> Tm;       // A * U_j
     DevBuf<double> partial, colsum, scal, rho_part, trace_own;
     DevBuf<ExpmPlan> plan_d;
+    DevBuf<int> viol_d;
     ExpmPlan* plan_h = nullptr;  // pinned
     ExpmPlan last{};
     size_t bs = 0;      // elements per block
@@ -115,6 +116,8 @@ template <typename T> struct ExpmEngine {
         MMW_TRY(rho_part.alloc(MAX_PART));
         MMW_TRY(trace_own.alloc(MAX_PART));
         MMW_TRY(plan_d.alloc(1));
+        MMW_TRY(viol_d.alloc(1));
+        MMW_HIP(hipMemsetAsync(viol_d.p, 0, sizeof(int), st));
         MMW_HIP(hipHostMalloc((void**)&plan_h, sizeof(ExpmPlan)));
         MMW_HIP(hipMemsetAsync(U.p, 0, bs * (size_t)(MAX_ORDER + 1) * sizeof(T), st));
         return MMW_OK;
@@ -131,12 +134,13 @@ template <typename T> struct ExpmEngine {
         return S;
     }
 
-    template <int MODE> int launch_spmm(const T* in, T* out, T* F, double ascale, double shift, double inv_k) {
+    template <int MODE> int launch_spmm(const T* in, T* out, T* F, double ascale, double shift, double inv_k,
+                                        const ExpmPlan* plan = nullptr, int step = 0) {
         MMW_TRY(kbegin(KT_SPMM));
         if (use_blk)
-            MMW_TRY((spmm_blk_launch<T, MODE>(st, blk, lay.Dpad, val_blk, in, out, F, nullptr, ascale, shift, inv_k, partial.p)));
+            MMW_TRY((spmm_blk_launch<T, MODE>(st, blk, lay.Dpad, val_blk, in, out, F, nullptr, ascale, shift, inv_k, partial.p, plan, step)));
         else
-            MMW_TRY((spmm_launch<T, MODE>(st, K, lay, nblk, indptr, col, val, in, out, F, nullptr, ascale, shift, inv_k, partial.p)));
+            MMW_TRY((spmm_launch<T, MODE>(st, K, lay, nblk, indptr, col, val, in, out, F, nullptr, ascale, shift, inv_k, partial.p, plan, step)));
         return kend();
     }
     int enable_blocking(const BlkDev& b, const T* values_blocked) {
@@ -147,14 +151,18 @@ template <typename T> struct ExpmEngine {
         if ((size_t)b.nb > (size_t)MAX_PART) MMW_TRY(partial.alloc((size_t)b.nb * lay.Dpad));
         return MMW_OK;
     }
-    int colreduce(int nb) {
-        hipLaunchKernelGGL(k_colreduce, dim3((lay.Dpad + 15) / 16), dim3(BLOCK), 0, st, nb, lay.Dpad, partial.p, colsum.p);
+    template <int OP> int colreduce(int nb, int j, const ExpmPlan* plan) {
+        const double eps = sizeof(T) == 4 ? 1e-6 : 1e-14;
+        hipLaunchKernelGGL((k_colreduce<OP>), dim3((lay.Dpad + 63) / 64), dim3(1024), 0, st, nb, lay.Dpad, partial.p, colsum.p, j, eps, scalars(), plan);
         MMW_HIP(hipGetLastError());
         return MMW_OK;
     }
 
-    // plan from the current values; trace_part: per-block diagonal sums made by the producer (or null)
-    int make_plan(double ascale, const double* trace_part, int ntrace) {
+    // plan from the current values; trace_part: per-block diagonal sums made by the producer (or null).
+    // m_launch == 0: read the plan back (one stream sync) and launch exactly what it asks for;
+    // m_launch  > 0: no readback -- the caller launches m_launch single-substep stages and the kernels
+    //                themselves skip the stages beyond the device-side order (viol is raised if it needs more).
+    int make_plan(double ascale, const double* trace_part, int ntrace, int m_launch) {
         if (!trace_part) {
             const int g = grid_elems((size_t)K);
             hipLaunchKernelGGL((k_tracepart<T>), dim3(g), dim3(BLOCK), 0, st, K, indptr, col, val, trace_own.p);
@@ -162,19 +170,37 @@ template <typename T> struct ExpmEngine {
             ntrace = g;
         }
         hipLaunchKernelGGL((k_rowabs<T>), dim3(nblk), dim3(BLOCK), 0, st, K, indptr, col, val, ascale, trace_part, ntrace, rho_part.p);
-        hipLaunchKernelGGL(k_plan, dim3(1), dim3(BLOCK), 0, st, K, method, max_order, tol, ascale, rho_part.p, nblk, trace_part, ntrace, plan_d.p);
+        hipLaunchKernelGGL(k_plan, dim3(1), dim3(BLOCK), 0, st, K, method, max_order, tol, ascale, rho_part.p, nblk, trace_part, ntrace, plan_d.p,
+                           m_launch, viol_d.p);
         MMW_HIP(hipGetLastError());
+        if (m_launch > 0) return MMW_OK;
         MMW_HIP(hipMemcpyAsync(plan_h, plan_d.p, sizeof(ExpmPlan), hipMemcpyDeviceToHost, st));
         MMW_HIP(hipStreamSynchronize(st));
         last = *plan_h;
         if (last.overflow) return fail(MMW_ERR_STATE, "expm: the one-norm of the matrix is too large for max_order (raise max_order)");
         return MMW_OK;
     }
+    // read the last plan and the sticky violation flag (synchronises the stream)
+    int fetch_plan(int* violated) {
+        int v = 0;
+        MMW_HIP(hipMemcpyAsync(plan_h, plan_d.p, sizeof(ExpmPlan), hipMemcpyDeviceToHost, st));
+        MMW_HIP(hipMemcpyAsync(&v, viol_d.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        MMW_HIP(hipStreamSynchronize(st));
+        last = *plan_h;
+        if (violated) *violated = v;
+        return MMW_OK;
+    }
+    int clear_violation() {
+        MMW_HIP(hipMemsetAsync(viol_d.p, 0, sizeof(int), st));
+        return MMW_OK;
+    }
 
     // out = exp(ascale*A) * start_block().  `out` must not alias the engine's blocks.
-    int apply(T* out, double ascale, const double* trace_part = nullptr, int ntrace = 0) {
-        MMW_TRY(make_plan(ascale, trace_part, ntrace));
-        const int m = last.m, nsub = last.nsub;
+    int apply(T* out, double ascale, const double* trace_part = nullptr, int ntrace = 0, int m_launch = 0) {
+        MMW_TRY(make_plan(ascale, trace_part, ntrace, m_launch));
+        const int m = m_launch > 0 ? m_launch : last.m;
+        const int nsub = m_launch > 0 ? 1 : last.nsub;
+        const ExpmPlan* pd = plan_d.p;
         const int Dpad = lay.Dpad;
         const int gcol = (Dpad + 63) / 64;
         const int gel = grid_elems(bs);
@@ -186,31 +212,33 @@ template <typename T> struct ExpmEngine {
             if (method == MMW_EXPM_LANCZOS) {
                 LanczosScalars S = scalars();
                 const int gr = grid_rows(K * 4);  // k_colsq / k_lz_update stride rows by workgroup
+                MMW_TRY(kbegin(KT_KRYLOV_VEC));
                 hipLaunchKernelGGL((k_colsq<T>), dim3(gr), dim3(BLOCK), shcol, st, K, Dpad, U.p, partial.p);
-                MMW_TRY(colreduce(gr));
-                hipLaunchKernelGGL(k_lz_init, dim3(gcol), dim3(64), 0, st, Dpad, colsum.p, S);
+                MMW_TRY((colreduce<LZ_INIT>(gr, 0, pd)));
+                MMW_TRY(kend());
                 for (int j = 1; j <= m; ++j) {
-                    MMW_TRY((launch_spmm<SPMM_LANCZOS>(block(j - 1), Tm.p, nullptr, ascale, 0.0, 1.0)));
-                    MMW_TRY(colreduce(npart));
-                    hipLaunchKernelGGL(k_lz_alpha, dim3(gcol), dim3(64), 0, st, Dpad, j, colsum.p, S);
+                    MMW_TRY((launch_spmm<SPMM_LANCZOS>(block(j - 1), Tm.p, nullptr, ascale, 0.0, 1.0, pd, j)));
+                    MMW_TRY(kbegin(KT_KRYLOV_VEC));
+                    MMW_TRY((colreduce<LZ_ALPHA>(npart, j, pd)));
                     if (j < m) {
                         hipLaunchKernelGGL((k_lz_update<T>), dim3(gr), dim3(BLOCK), shcol, st, K, Dpad, j, Tm.p, block(j - 1),
-                                           j > 1 ? block(j - 2) : block(j - 1), block(j), S, partial.p);
-                        MMW_TRY(colreduce(gr));
-                        const double eps = sizeof(T) == 4 ? 1e-6 : 1e-14;
-                        hipLaunchKernelGGL(k_lz_beta, dim3(gcol), dim3(64), 0, st, Dpad, j, eps, colsum.p, S);
+                                           j > 1 ? block(j - 2) : block(j - 1), block(j), S, partial.p, pd);
+                        MMW_TRY((colreduce<LZ_BETA>(gr, j, pd)));
                     }
+                    MMW_TRY(kend());
                 }
-                hipLaunchKernelGGL(k_lz_texp, dim3(gcol), dim3(64), 0, st, Dpad, m, 1.0 / nsub, S);
-                hipLaunchKernelGGL((k_lz_combine<T>), dim3(gel), dim3(BLOCK), 0, st, K, Dpad, m, U.p, bs, S.coef, out);
+                MMW_TRY(kbegin(KT_KRYLOV_VEC));
+                hipLaunchKernelGGL(k_lz_texp, dim3(gcol), dim3(64), 0, st, Dpad, m, 1.0 / nsub, S, pd);
+                hipLaunchKernelGGL((k_lz_combine<T>), dim3(gel), dim3(BLOCK), 0, st, K, Dpad, m, U.p, bs, S.coef, out, pd);
+                MMW_TRY(kend());
             } else {
                 hipLaunchKernelGGL((k_copy<T>), dim3(gel), dim3(BLOCK), 0, st, bs, U.p, out);
                 for (int k = 1; k <= m; ++k) {
                     T* in = k == 1 ? U.p : block((k - 1) % 2 + 1);
                     T* o = block(k % 2 + 1);
-                    MMW_TRY((launch_spmm<SPMM_TAYLOR>(in, o, out, ascale / nsub, last.mu / nsub, 1.0 / k)));
+                    MMW_TRY((launch_spmm<SPMM_TAYLOR>(in, o, out, ascale / nsub, last.mu / nsub, 1.0 / k, pd, k)));
                 }
-                hipLaunchKernelGGL((k_scale<T>), dim3(gel), dim3(BLOCK), 0, st, bs, out, std::exp(last.mu / nsub));
+                hipLaunchKernelGGL((k_scale<T>), dim3(gel), dim3(BLOCK), 0, st, bs, out, 1.0, pd);
             }
             MMW_HIP(hipGetLastError());
         }

@@ -37,8 +37,12 @@ __global__ __launch_bounds__(BLOCK) void k_spmm(int K, BlockLayout lay, const in
                                                 const int* __restrict__ col, const T* __restrict__ val,
                                                 const T* __restrict__ U, T* __restrict__ Out, T* __restrict__ F,
                                                 const T* __restrict__ X2, double ascale, double shift, double inv_k,
-                                                double* __restrict__ partial) {
+                                                double* __restrict__ partial, const ExpmPlan* __restrict__ plan, int step) {
     constexpr int VEC = V16<T>::N;
+    if (plan) {  // device-side order: steps beyond the planned Krylov order are no-ops
+        if (step > plan->m) return;
+        if (MODE == SPMM_TAYLOR) shift = plan->mu / plan->nsub;
+    }
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     const int LPR = lay.LPR, G = lay.G, Dpad = lay.Dpad;
@@ -208,9 +212,14 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, int ntiles, int tpw, const T* __restrict__ val_blk,
                                                           const T* __restrict__ U, T* __restrict__ Out, T* __restrict__ F,
                                                           const T* __restrict__ X2, double ascale, double shift, double inv_k,
-                                                          double* __restrict__ partial, int dbg) {
+                                                          double* __restrict__ partial, const ExpmPlan* __restrict__ plan, int step) {
     constexpr int VEC = V16<T>::N;
     constexpr int CT = BLK_TILE_BYTES / (int)sizeof(T);  // columns per tile
+    constexpr int dbg = 0;
+    if (plan) {
+        if (step > plan->m) return;
+        if (MODE == SPMM_TAYLOR) shift = plan->mu / plan->nsub;
+    }
     constexpr int RPP = BLK_THREADS / 16;                // union rows gathered per pass
     constexpr int NG = BLK_UNION_ROWS / RPP;             // gathers per thread
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -385,24 +394,9 @@ __global__ __launch_bounds__(BLOCK) void k_colsq(int K, int Dpad, const T* __res
     }
 }
 
-// out[col] = sum_b partial[b][col]; one workgroup per 16 columns, 16 threads per column.
-__global__ __launch_bounds__(BLOCK) void k_colreduce(int nb, int Dpad, const double* __restrict__ partial,
-                                                      double* __restrict__ out) {
-    __shared__ double sh[BLOCK];
-    const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;  // 16 cols x 16 parts
-    const int c = blockIdx.x * 16 + cl;
-    double s = 0.0;
-    if (c < Dpad)
-        for (int b = part; b < nb; b += 16) s += partial[(size_t)b * Dpad + c];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    if (part == 0 && c < Dpad) {
-        double t = 0.0;
-        for (int p = 0; p < 16; ++p) t += sh[p * 16 + cl];
-        out[c] = t;
-    }
-}
-
+// out[col] = sum_b partial[b][col] in a fixed order: one workgroup per 64 columns, 16 row slices per column,
+// reads coalesced across columns.  The Lanczos scalar update that consumes the sum is fused in (OP).
+enum { LZ_NONE = 0, LZ_INIT = 1, LZ_ALPHA = 2, LZ_BETA = 3 };
 // Lanczos scalars, per column c (all arrays [MAX_ORDER+2][Dpad], index j = Lanczos step starting at 1):
 //   beta[0] = ||b_c||, sinv[j] = 1/beta[j-1] (0 when the Krylov space is exhausted), alpha[j].
 struct LanczosScalars {
@@ -412,27 +406,47 @@ struct LanczosScalars {
     double* coef;  // [MAX_ORDER+1][Dpad]: y = sum_j coef[j] U_j
 };
 
-// after k_colsq of the start block: beta0, sinv1
-__global__ void k_lz_init(int Dpad, const double* __restrict__ colsq, LanczosScalars S) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= Dpad) return;
-    const double b = sqrt(colsq[c]);
-    S.beta[c] = b;
-    S.sinv[1 * Dpad + c] = b > 0.0 ? 1.0 / b : 0.0;
-}
-// after SpMM step j: alpha_j = sinv_j^2 * (U_j . A U_j)
-__global__ void k_lz_alpha(int Dpad, int j, const double* __restrict__ dotsum, LanczosScalars S) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= Dpad) return;
-    const double s = S.sinv[j * Dpad + c];
-    S.alpha[j * Dpad + c] = s * s * dotsum[c];
+template <int OP>
+__global__ __launch_bounds__(1024) void k_colreduce(int nb, int Dpad, const double* __restrict__ partial, double* __restrict__ out, int j,
+                                                    double eps, LanczosScalars S, const ExpmPlan* __restrict__ plan) {
+    __shared__ double sh[16][64];
+    if (plan && ((OP == LZ_ALPHA && j > plan->m) || (OP == LZ_BETA && j >= plan->m))) return;
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double s = 0.0;
+    if (c < Dpad)
+        for (int b = sl; b < nb; b += 16) s += partial[(size_t)b * Dpad + c];
+    sh[sl][cl] = s;
+    __syncthreads();
+    if (sl == 0 && c < Dpad) {
+        double t = 0.0;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) t += sh[p][cl];
+        if (OP == LZ_NONE) {
+            out[c] = t;
+        } else if (OP == LZ_INIT) {  // beta0 = ||b_c||, sinv1
+            const double b = sqrt(t);
+            S.beta[c] = b;
+            S.sinv[1 * Dpad + c] = b > 0.0 ? 1.0 / b : 0.0;
+        } else if (OP == LZ_ALPHA) {  // alpha_j = sinv_j^2 (U_j . A U_j)
+            const double si = S.sinv[j * Dpad + c];
+            S.alpha[j * Dpad + c] = si * si * t;
+        } else {  // beta_j = ||U_{j+1}||, sinv_{j+1}; a column at rounding level has exhausted its Krylov space
+            const double b = sqrt(t);
+            const double scale = fabs(S.alpha[j * Dpad + c]) + (j > 1 ? S.beta[(j - 1) * Dpad + c] : 0.0);
+            const bool dead = S.sinv[j * Dpad + c] == 0.0 || !(b > eps * scale) || !(b > 0.0);
+            S.beta[j * Dpad + c] = dead ? 0.0 : b;
+            S.sinv[(j + 1) * Dpad + c] = dead ? 0.0 : 1.0 / b;
+        }
+    }
 }
 // U_{j+1} = sinv_j * t - alpha_j sinv_j U_j - beta_{j-1} sinv_{j-1} U_{j-1};  partial col sums of U_{j+1}^2
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_lz_update(int K, int Dpad, int j, const T* __restrict__ Tm, const T* __restrict__ Uj,
                                                      const T* __restrict__ Ujm1, T* __restrict__ Unext, LanczosScalars S,
-                                                     double* __restrict__ partial) {
+                                                     double* __restrict__ partial, const ExpmPlan* __restrict__ plan) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    if (plan && j >= plan->m) return;  // U_{m+1} is never used
     double* sh = reinterpret_cast<double*>(smem_raw);  // [BLOCK]
     const int rpp = BLOCK / Dpad > 0 ? BLOCK / Dpad : 1;
     for (int c0 = 0; c0 < Dpad; c0 += BLOCK) {
@@ -464,24 +478,17 @@ __global__ __launch_bounds__(BLOCK) void k_lz_update(int K, int Dpad, int j, con
         __syncthreads();
     }
 }
-// beta_j = ||U_{j+1}||, sinv_{j+1}.  A column whose new vector is at rounding level relative to the
-// recurrence terms has exhausted its Krylov space: it is frozen (all later vectors zero).
-__global__ void k_lz_beta(int Dpad, int j, double breakdown_eps, const double* __restrict__ colsq, LanczosScalars S) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= Dpad) return;
-    const double b = sqrt(colsq[c]);
-    const double scale = fabs(S.alpha[j * Dpad + c]) + (j > 1 ? S.beta[(j - 1) * Dpad + c] : 0.0);
-    const bool dead = S.sinv[j * Dpad + c] == 0.0 || !(b > breakdown_eps * scale) || !(b > 0.0);
-    S.beta[j * Dpad + c] = dead ? 0.0 : b;
-    S.sinv[(j + 1) * Dpad + c] = dead ? 0.0 : 1.0 / b;
-}
 // per column: g = exp(T_m / nsub) e_1 for the m x m tridiagonal T (alpha_1..m, beta_1..m-1);
 // coef[j] = beta0 * g_j * sinv_j  so that  y = sum_j coef[j] U_j.
 // exp(T) e_1 by a scaled Taylor series on the m-vector (||T|| is small here; squaring by repeated
 // application keeps it valid for any norm).
-__global__ void k_lz_texp(int Dpad, int m, double inv_nsub, LanczosScalars S) {
+__global__ void k_lz_texp(int Dpad, int m, double inv_nsub, LanczosScalars S, const ExpmPlan* __restrict__ plan) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= Dpad) return;
+    if (plan) {
+        m = plan->m;
+        inv_nsub = 1.0 / plan->nsub;
+    }
     double a[MAX_ORDER], b[MAX_ORDER], g[MAX_ORDER], t[MAX_ORDER], f[MAX_ORDER];
     double nrm = 0.0, mu = 0.0;
     int mm = m;
@@ -534,7 +541,9 @@ __global__ void k_lz_texp(int Dpad, int m, double inv_nsub, LanczosScalars S) {
 // y[row,:] = sum_{j=1..m} coef[j][:] * U_j[row,:]  (U_j = Ubase + (j-1)*stride)
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_lz_combine(int K, int Dpad, int m, const T* __restrict__ Ubase, size_t stride,
-                                                      const double* __restrict__ coef, T* __restrict__ Yout) {
+                                                      const double* __restrict__ coef, T* __restrict__ Yout,
+                                                      const ExpmPlan* __restrict__ plan) {
+    if (plan) m = plan->m;
     const size_t n = (size_t)K * Dpad;
     for (size_t o = (size_t)blockIdx.x * BLOCK + threadIdx.x; o < n; o += (size_t)gridDim.x * BLOCK) {
         const int c = (int)(o % Dpad);
@@ -544,7 +553,9 @@ __global__ __launch_bounds__(BLOCK) void k_lz_combine(int K, int Dpad, int m, co
     }
 }
 // y *= scale (Taylor: e^{mu})
-template <typename T> __global__ __launch_bounds__(BLOCK) void k_scale(size_t n, T* __restrict__ y, double scale) {
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_scale(size_t n, T* __restrict__ y, double scale, const ExpmPlan* __restrict__ plan) {
+    if (plan) scale = exp(plan->mu / plan->nsub);
     for (size_t o = (size_t)blockIdx.x * BLOCK + threadIdx.x; o < n; o += (size_t)gridDim.x * BLOCK)
         y[o] = (T)((double)y[o] * scale);
 }
@@ -629,8 +640,11 @@ __host__ __device__ inline int plan_order(int method, double rho, double tol, in
     return -1;
 }
 
+// m_launch > 0: the host has already decided to launch m_launch steps with a single substep (no readback);
+// if the matrix needs more, the sticky flag *viol is raised and the caller replays the batch synchronously.
 __global__ void k_plan(int K, int method, int max_order, double tol, double ascale, const double* __restrict__ rho_part, int nrho,
-                       const double* __restrict__ trace_part, int ntrace, ExpmPlan* __restrict__ plan) {
+                       const double* __restrict__ trace_part, int ntrace, ExpmPlan* __restrict__ plan, int m_launch,
+                       int* __restrict__ viol) {
     __shared__ double sh[WAVES_PER_BLOCK];
     double r = 0.0, tr = 0.0;
     for (int i = threadIdx.x; i < nrho; i += blockDim.x) r = rho_part[i] > r ? rho_part[i] : r;
@@ -655,6 +669,11 @@ __global__ void k_plan(int K, int method, int max_order, double tol, double asca
         }
         p.m = m;
         p.nsub = nsub;
+        if (m_launch > 0 && (nsub > 1 || m > m_launch || p.overflow)) {
+            *viol = 1;
+            p.m = m < m_launch ? m : m_launch;  // keep the launched kernels in range; the batch is replayed anyway
+            p.nsub = 1;
+        }
         *plan = p;
     }
 }

@@ -394,32 +394,57 @@ __global__ __launch_bounds__(BLK_THREADS) void k_sddmm_blk(BlkDev B, SdDev S, Pa
 }
 
 // ---- on-device Gaussian sketch: rows of unit 2-norm (mmw.py:226-227) -----------------------------
+// One wavefront per row, one pass: every lane draws its 16 bytes of the row (4 floats / 2 doubles) per
+// step from Philox4x32-10 keyed by (seed; row, column group, iteration), keeps them in registers, the
+// wave reduces the squared norm and the normalised row is written with one 16-B store per lane.
+__device__ __forceinline__ void normals16(const uint32_t (&w)[4], float (&n)[4]) {
+    const float u1 = (float)((w[0] >> 8) + 1u) * 5.9604644775390625e-8f;  // (0, 1]
+    const float u2 = (float)(w[1] >> 8) * 5.9604644775390625e-8f;
+    const float u3 = (float)((w[2] >> 8) + 1u) * 5.9604644775390625e-8f;
+    const float u4 = (float)(w[3] >> 8) * 5.9604644775390625e-8f;
+    const float r1 = sqrtf(-2.0f * __logf(u1)), r2 = sqrtf(-2.0f * __logf(u3));
+    float s1, c1, s2, c2;
+    sincospif(2.0f * u2, &s1, &c1);
+    sincospif(2.0f * u4, &s2, &c2);
+    n[0] = r1 * c1; n[1] = r1 * s1; n[2] = r2 * c2; n[3] = r2 * s2;
+}
+__device__ __forceinline__ void normals16(const uint32_t (&w)[4], double (&n)[2]) { box_muller(w, n[0], n[1]); }
+
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_sketch_rng(int K, int D, int Dpad, uint64_t seed, uint32_t iter, T* __restrict__ R) {
+    constexpr int VEC = V16<T>::N;
+    constexpr int NS = 4;  // 64 lanes x 4 steps x 16 B covers Dpad <= 1024 floats / 512 doubles
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int ngroups = Dpad / VEC;
     for (int row = blockIdx.x * WAVES_PER_BLOCK + wib; row < K; row += gridDim.x * WAVES_PER_BLOCK) {
+        T n[NS][VEC];
         double ss = 0.0;
-        // each lane produces pairs of columns (2p, 2p+1)
-        for (int p = lane; 2 * p < Dpad; p += WAVE) {
-            uint32_t w[4];
-            philox4x32_10((uint32_t)row, (uint32_t)p, iter, 0x4d4d5753u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
-            double n0, n1;
-            box_muller(w, n0, n1);
-            if (2 * p >= D) n0 = 0.0;
-            if (2 * p + 1 >= D) n1 = 0.0;
-            ss += n0 * n0 + n1 * n1;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int p = lane + WAVE * i;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) n[i][v] = T(0);
+            if (p < ngroups) {
+                uint32_t w[4];
+                philox4x32_10((uint32_t)row, (uint32_t)p, iter, 0x4d4d5753u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+                normals16(w, n[i]);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    if (p * VEC + v >= D) n[i][v] = T(0);
+                    ss += (double)n[i][v] * (double)n[i][v];
+                }
+            }
         }
         ss = wave_sum(ss);
-        const double inv = ss > 0.0 ? 1.0 / sqrt(ss) : 0.0;
-        for (int p = lane; 2 * p < Dpad; p += WAVE) {
-            uint32_t w[4];
-            philox4x32_10((uint32_t)row, (uint32_t)p, iter, 0x4d4d5753u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
-            double n0, n1;
-            box_muller(w, n0, n1);
-            if (2 * p >= D) n0 = 0.0;
-            if (2 * p + 1 >= D) n1 = 0.0;
-            R[(size_t)row * Dpad + 2 * p] = (T)(n0 * inv);
-            if (2 * p + 1 < Dpad) R[(size_t)row * Dpad + 2 * p + 1] = (T)(n1 * inv);
+        const T inv = (T)(ss > 0.0 ? 1.0 / sqrt(ss) : 0.0);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int p = lane + WAVE * i;
+            if (p < ngroups) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) n[i][v] *= inv;
+                store16(R + (size_t)row * Dpad + (size_t)p * VEC, n[i]);
+            }
         }
     }
 }

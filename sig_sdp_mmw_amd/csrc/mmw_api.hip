@@ -54,6 +54,12 @@ template <typename T> struct Solver final : mmw_solver {
     bool sddmm_blk = false;
     DevBuf<T> lval_blk;
     int blocking_mode = 1;  // 1: use when profitable, 0: never
+    // optimistic (no per-iteration readback) batches: snapshot for the rare replay
+    DevBuf<T> sn_lval, sn_lblk, sn_xval, sn_xavg, sn_Y, sn_yavg, sn_eaccu;
+    bool pending = false;
+    int pend_iter0 = 0, pend_n = 0, m_guess = 3;
+    uint64_t pend_seed = 0;
+    int replays = 0;
     ExpmEngine<T> eng;
     Extras<T> extras;
     KernelTimers kt;
@@ -209,6 +215,9 @@ template <typename T> struct Solver final : mmw_solver {
         if (nit_ < 1) return fail(MMW_ERR_ARG, "nit must be >= 1");
         nit = nit_;
         iter = 0;
+        pending = false;
+        m_guess = 3;
+        if (eng.viol_d.p) MMW_TRY(eng.clear_violation());
         const size_t nnz = (size_t)H.nnzL(), C = (size_t)H.C();
         MMW_HIP(hipMemsetAsync(lval.p, 0, nnz * sizeof(T), st));
         if (lval_blk.p) MMW_HIP(hipMemsetAsync(lval_blk.p, 0, (size_t)HB.nent * sizeof(T), st));
@@ -250,17 +259,67 @@ template <typename T> struct Solver final : mmw_solver {
         return MMW_OK;
     }
 
+    int copy_state(bool save) {
+        const size_t nnz = (size_t)H.nnzL(), C = (size_t)H.C();
+        auto cp = [&](DevBuf<T>& snap, DevBuf<T>& live, size_t n) -> int {
+            if (!live.p || n == 0) return MMW_OK;
+            if (snap.n < n) MMW_TRY(snap.alloc(n));
+            MMW_HIP(hipMemcpyAsync(save ? snap.p : live.p, save ? live.p : snap.p, n * sizeof(T), hipMemcpyDeviceToDevice, st));
+            return MMW_OK;
+        };
+        MMW_TRY(cp(sn_lval, lval, nnz)); MMW_TRY(cp(sn_lblk, lval_blk, lval_blk.p ? (size_t)HB.nent : 0)); MMW_TRY(cp(sn_xval, xval, nnz));
+        MMW_TRY(cp(sn_xavg, xavg, nnz)); MMW_TRY(cp(sn_Y, Y, C)); MMW_TRY(cp(sn_yavg, yavg, C)); MMW_TRY(cp(sn_eaccu, e_accu, C));
+        return MMW_OK;
+    }
+    // a batch enqueued without plan readbacks is verified here; a violated batch is replayed synchronously
+    int settle() {
+        if (!pending) return MMW_OK;
+        pending = false;
+        int viol = 0;
+        MMW_TRY(eng.fetch_plan(&viol));
+        if (!viol) {
+            m_guess = std::min(eng.max_order, eng.last.m + 1);
+            return MMW_OK;
+        }
+        ++replays;
+        MMW_TRY(eng.clear_violation());
+        MMW_TRY(copy_state(false));
+        iter = pend_iter0;
+        if (timing) {  // drop the timers of the discarded batch
+            MMW_HIP(hipStreamSynchronize(st));
+            for (auto e : events) (void)hipEventDestroy(e);
+            events.clear();
+        }
+        return iterate_impl(pend_n, nullptr, pend_seed, false);
+    }
     int iterate(int32_t n, const double* randv, uint64_t seed) override {
         if (host_only) return fail(MMW_ERR_STATE, "this handle was created with device -1 (host pattern only)");
         MMW_HIP(hipSetDevice(device));
         if (n < 0) return fail(MMW_ERR_ARG, "n must be >= 0");
+        MMW_TRY(settle());
         if (iter + n > nit) return fail(MMW_ERR_STATE, "mmw_iterate: more iterations than announced to mmw_create/mmw_reset");
+        const bool optimistic = randv == nullptr && n > 1 && !getenv("MMW_SYNC_PLAN");
+        if (optimistic) {
+            MMW_TRY(copy_state(true));
+            pend_iter0 = iter; pend_n = n; pend_seed = seed;
+        }
+        MMW_TRY(iterate_impl(n, randv, seed, optimistic));
+        pending = optimistic;
+        return MMW_OK;
+    }
+    int iterate_impl(int32_t n, const double* randv, uint64_t seed, bool optimistic) {
         const PatternDev<T> P = pat();
         const int gr = grid_rows(K);
         const int C = (int)H.C();
         const int gc = grid_elems((size_t)C);
         const int Dpad = eng.lay.Dpad;
+        int m_launch = optimistic ? m_guess : 0;
         for (int it = 0; it < n; ++it) {
+            if (optimistic && it > 0 && it % 16 == 0) {  // cheap periodic look at the device-side order
+                int viol = 0;
+                MMW_TRY(eng.fetch_plan(&viol));
+                if (!viol) m_launch = m_guess = std::min(eng.max_order, eng.last.m + 1);
+            }
             const int acc = (iter + 1 < nit) ? 1 : 0;  // the last X / Y are not averaged (mmw.py:77-78,203)
             MMW_TRY(record(0));
             // ---- DUAL
@@ -290,7 +349,7 @@ template <typename T> struct Solver final : mmw_solver {
             }
             MMW_TRY(kt.end());
             MMW_HIP(hipGetLastError());
-            MMW_TRY(eng.apply(Xh.p, 0.5, trace_part.p, gr));
+            MMW_TRY(eng.apply(Xh.p, 0.5, trace_part.p, gr, m_launch));
             MMW_TRY(kt.begin(KT_SDDMM));
             hipLaunchKernelGGL((k_rownorm2<T>), dim3(gr), dim3(BLOCK), 0, st, K, Dpad, Xh.p, drow.p, tr_part.p);
             if (sddmm_blk && eng.use_blk) {
@@ -318,6 +377,7 @@ template <typename T> struct Solver final : mmw_solver {
     int sync() override {
         if (host_only) return fail(MMW_ERR_STATE, "this handle was created with device -1 (host pattern only)");
         MMW_HIP(hipSetDevice(device));
+        MMW_TRY(settle());
         MMW_HIP(hipStreamSynchronize(st));
         MMW_TRY(kt.flush());
         return flush_events();
@@ -382,7 +442,7 @@ template <typename T> struct Solver final : mmw_solver {
             }
             case MMW_F_BLOCKING: {
                 if (n != 4) return fail(MMW_ERR_ARG, "blocking info has 4 entries");
-                out[0] = eng.use_blk ? 1.0 : 0.0; out[1] = HB.usable ? HB.nb() : 0; out[2] = HB.reuse; out[3] = (double)HB.un_cols.size();
+                out[0] = eng.use_blk ? 1.0 : 0.0; out[1] = HB.usable ? HB.nb() : 0; out[2] = HB.reuse; out[3] = (double)replays;
                 return MMW_OK;
             }
             case MMW_F_FACTOR: return extras.read_factor(out, n);
@@ -417,12 +477,14 @@ template <typename T> struct Solver final : mmw_solver {
     int gap(double out[3]) override {
         if (host_only) return fail(MMW_ERR_STATE, "host-only handle");
         MMW_HIP(hipSetDevice(device));
+        MMW_TRY(settle());
         if (iter >= nit) return fail(MMW_ERR_STATE, "mmw_gap: call it before an iteration (the running sums then hold iter+1 terms)");
         return extras.gap(pat(), xavg.p, yavg.p, iter + 1, out);
     }
     int factor(int32_t rank, double* out, uint64_t seed) override {
         if (host_only) return fail(MMW_ERR_STATE, "host-only handle");
         MMW_HIP(hipSetDevice(device));
+        MMW_TRY(settle());
         if (iter < nit) return fail(MMW_ERR_STATE, "mmw_factor: run all announced iterations first (the average divides by nit)");
         return extras.factor(d_indptr.p, d_col.p, xavg.p, nit, rank, out, seed);
     }
