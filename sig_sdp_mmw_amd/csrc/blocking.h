@@ -11,6 +11,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <numeric>
 #include <queue>
 #include <vector>
@@ -112,10 +113,13 @@ inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& i
     B.un_cols.clear();
     std::vector<int32_t> stamp(K, -1), cur;
     int blk = 0, p = 0;
+    const int row_cap = getenv("MMW_BLK_ROWS") ? atoi(getenv("MMW_BLK_ROWS")) : BLK_ROWS;
+    const int row_quant = getenv("MMW_BLK_QUANT") ? atoi(getenv("MMW_BLK_QUANT")) : 1;
     while (p < K) {
         cur.clear();
         int rows = 0, entries = 0;
-        while (p < K && rows < BLK_ROWS) {
+        const int p_start = p;
+        while (p < K && rows < row_cap) {
             const int r = B.order[p];
             int fresh = 0;
             for (int e = indptr[r]; e < indptr[r + 1]; ++e)
@@ -130,6 +134,20 @@ inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& i
                 }
             ++rows;
             ++p;
+        }
+        if (row_quant > 1 && rows > row_quant && rows % row_quant && p < K) {  // trim to a multiple of the wave count
+            const int keep = rows / row_quant * row_quant;
+            p = p_start + keep;
+            cur.clear();
+            ++blk;  // fresh stamp generation for the rebuilt union
+            for (int q = p_start; q < p; ++q) {
+                const int r = B.order[q];
+                for (int e = indptr[r]; e < indptr[r + 1]; ++e)
+                    if (stamp[indices[e]] != blk) {
+                        stamp[indices[e]] = blk;
+                        cur.push_back(indices[e]);
+                    }
+            }
         }
         std::sort(cur.begin(), cur.end(), [&](int a, int b) { return rank[a] < rank[b]; });
         B.un_cols.insert(B.un_cols.end(), cur.begin(), cur.end());

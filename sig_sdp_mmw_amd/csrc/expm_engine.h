@@ -47,6 +47,7 @@ inline int spmm_launch(hipStream_t st, int K, const BlockLayout& lay, int nblk, 
     return MMW_OK;
 }
 
+inline unsigned long long* g_blk_stamps = nullptr;  // diagnostic builds only: per-workgroup phase stamps
 // one launch of the LDS-staged blocked SpMM (values in blocked order)
 template <typename T, int MODE>
 inline int spmm_blk_launch(hipStream_t st, const BlkDev& B, int Dpad, const T* val_blk, const T* in, T* out, T* F, const T* X2,
@@ -63,7 +64,7 @@ inline int spmm_blk_launch(hipStream_t st, const BlkDev& B, int Dpad, const T* v
         MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_blk<T, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_spmm_blk<T, MODE>), dim3(per * 8), dim3(BLK_THREADS), sh, st, B, Dpad, ntiles, tpw, val_blk, in, out, F, X2, c1, c2, c3, partial, plan, step);
+    hipLaunchKernelGGL((k_spmm_blk<T, MODE>), dim3(per * 8), dim3(BLK_THREADS), sh, st, B, Dpad, ntiles, tpw, val_blk, in, out, F, X2, c1, c2, c3, partial, plan, step, g_blk_stamps);
     MMW_HIP(hipGetLastError());
     return MMW_OK;
 }
@@ -220,11 +221,10 @@ template <typename T> struct ExpmEngine {
                     MMW_TRY((launch_spmm<SPMM_LANCZOS>(block(j - 1), Tm.p, nullptr, ascale, 0.0, 1.0, pd, j)));
                     MMW_TRY(kbegin(KT_KRYLOV_VEC));
                     MMW_TRY((colreduce<LZ_ALPHA>(npart, j, pd)));
-                    if (j < m) {
-                        hipLaunchKernelGGL((k_lz_update<T>), dim3(gr), dim3(BLOCK), shcol, st, K, Dpad, j, Tm.p, block(j - 1),
-                                           j > 1 ? block(j - 2) : block(j - 1), block(j), S, partial.p, pd);
-                        MMW_TRY((colreduce<LZ_BETA>(gr, j, pd)));
-                    }
+                    // also for j = m: U_{m+1} = beta_m v_{m+1} feeds the corrected scheme (no further SpMM)
+                    hipLaunchKernelGGL((k_lz_update<T>), dim3(gr), dim3(BLOCK), shcol, st, K, Dpad, j, Tm.p, block(j - 1),
+                                       j > 1 ? block(j - 2) : block(j - 1), block(j), S, partial.p, pd);
+                    MMW_TRY((colreduce<LZ_BETA>(gr, j, pd)));
                     MMW_TRY(kend());
                 }
                 MMW_TRY(kbegin(KT_KRYLOV_VEC));

@@ -212,10 +212,13 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, int ntiles, int tpw, const T* __restrict__ val_blk,
                                                           const T* __restrict__ U, T* __restrict__ Out, T* __restrict__ F,
                                                           const T* __restrict__ X2, double ascale, double shift, double inv_k,
-                                                          double* __restrict__ partial, const ExpmPlan* __restrict__ plan, int step) {
+                                                          double* __restrict__ partial, const ExpmPlan* __restrict__ plan, int step,
+                                                          unsigned long long* __restrict__ stamps) {
     constexpr int VEC = V16<T>::N;
     constexpr int CT = BLK_TILE_BYTES / (int)sizeof(T);  // columns per tile
     constexpr int dbg = 0;
+#define MMW_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    MMW_STAMP(0);
     if (plan) {
         if (step > plan->m) return;
         if (MODE == SPMM_TAYLOR) shift = plan->mu / plan->nsub;
@@ -263,6 +266,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, in
         for (int j = 0; j < NG; ++j)
             if (u0 + j * RPP < nun) store16(tile + (size_t)(u0 + j * RPP) * CT + l16 * VEC, x[j]);
     };
+    MMW_STAMP(1);
     gather(t0);
     for (int i = threadIdx.x; i < nmeta; i += BLK_THREADS) {  // the block's entries, once for all its tiles
         BlkMeta<T> e;
@@ -270,8 +274,11 @@ __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, in
         e.v = val_blk[m0 + i];
         meta[i] = e;
     }
+    MMW_STAMP(2);
     deposit();
+    MMW_STAMP(3);
     __syncthreads();
+    MMW_STAMP(4);
     for (int t = t0; t < t1; ++t) {
         if (t + 1 < t1) gather(t + 1);  // next tile's rows fly while this tile is consumed from LDS
         const int col0 = t * CT;
@@ -349,7 +356,9 @@ __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, in
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) shdot[wib * CT + l16 * VEC + v] = dot[v];
         }
+        if (t == t0) MMW_STAMP(5);
         __syncthreads();  // every wave is done with this tile (and shdot is complete)
+        if (t == t0) MMW_STAMP(6);
         if (MODE == SPMM_LANCZOS) {
             for (int c = threadIdx.x; c < CT; c += BLK_THREADS)
                 if (col0 + c < Dpad) {
@@ -360,9 +369,13 @@ __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, in
         }
         if (t + 1 < t1) {
             deposit();
+            if (t == t0) MMW_STAMP(7);
             __syncthreads();
+            if (t == t0) MMW_STAMP(8);
         }
     }
+    MMW_STAMP(9);
+#undef MMW_STAMP
 }
 
 // Column sums of squares of a block: partial[block][col] = sum over the block's rows of X^2.
@@ -410,7 +423,7 @@ template <int OP>
 __global__ __launch_bounds__(1024) void k_colreduce(int nb, int Dpad, const double* __restrict__ partial, double* __restrict__ out, int j,
                                                     double eps, LanczosScalars S, const ExpmPlan* __restrict__ plan) {
     __shared__ double sh[16][64];
-    if (plan && ((OP == LZ_ALPHA && j > plan->m) || (OP == LZ_BETA && j >= plan->m))) return;
+    if (plan && OP != LZ_INIT && OP != LZ_NONE && j > plan->m) return;
     const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     double s = 0.0;
@@ -446,7 +459,7 @@ __global__ __launch_bounds__(BLOCK) void k_lz_update(int K, int Dpad, int j, con
                                                      const T* __restrict__ Ujm1, T* __restrict__ Unext, LanczosScalars S,
                                                      double* __restrict__ partial, const ExpmPlan* __restrict__ plan) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    if (plan && j >= plan->m) return;  // U_{m+1} is never used
+    if (plan && j > plan->m) return;  // steps beyond the planned order
     double* sh = reinterpret_cast<double*>(smem_raw);  // [BLOCK]
     const int rpp = BLOCK / Dpad > 0 ? BLOCK / Dpad : 1;
     for (int c0 = 0; c0 < Dpad; c0 += BLOCK) {
@@ -478,10 +491,13 @@ __global__ __launch_bounds__(BLOCK) void k_lz_update(int K, int Dpad, int j, con
         __syncthreads();
     }
 }
-// per column: g = exp(T_m / nsub) e_1 for the m x m tridiagonal T (alpha_1..m, beta_1..m-1);
-// coef[j] = beta0 * g_j * sinv_j  so that  y = sum_j coef[j] U_j.
-// exp(T) e_1 by a scaled Taylor series on the m-vector (||T|| is small here; squaring by repeated
-// application keeps it valid for any norm).
+// per column: the corrected Krylov approximation (Saad 1992) of exp(A/nsub) b from m Lanczos steps:
+//   y = beta0 * [ V_m exp(T_m) e_1 + beta_m (e_m^T phi_1(T_m) e_1) v_{m+1} ],
+// i.e. the first column of exp of the (m+1) x (m+1) augmented matrix [[T_m, 0], [beta_m e_m^T, 0]].
+// It spends the direction A v_m that the m-th SpMM produced anyway, which buys one polynomial degree:
+// m SpMMs reach the accuracy of a degree-m Taylor polynomial.  coef[j] = beta0 * g_j * sinv_j, j = 1..m+1.
+// exp(M) e_1 by a scaled Taylor series on the small vector (||M|| is tiny here; repeated application keeps it
+// valid for any norm).
 __global__ void k_lz_texp(int Dpad, int m, double inv_nsub, LanczosScalars S, const ExpmPlan* __restrict__ plan) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= Dpad) return;
@@ -489,56 +505,59 @@ __global__ void k_lz_texp(int Dpad, int m, double inv_nsub, LanczosScalars S, co
         m = plan->m;
         inv_nsub = 1.0 / plan->nsub;
     }
-    double a[MAX_ORDER], b[MAX_ORDER], g[MAX_ORDER], t[MAX_ORDER], f[MAX_ORDER];
-    double nrm = 0.0, mu = 0.0;
-    int mm = m;
+    double a[MAX_ORDER + 1], b[MAX_ORDER + 1], g[MAX_ORDER + 1], t[MAX_ORDER + 1], f[MAX_ORDER + 1];
+    double nrm = 0.0;
+    int mm = m;  // Krylov dimension actually reached
     for (int j = 0; j < m; ++j) {
         a[j] = S.alpha[(j + 1) * Dpad + c] * inv_nsub;
-        b[j] = j + 1 < m ? S.beta[(j + 1) * Dpad + c] * inv_nsub : 0.0;
+        b[j] = S.beta[(j + 1) * Dpad + c] * inv_nsub;  // b[j] couples j and j+1; b[m-1] = beta_m feeds the correction
     }
-    for (int j = 0; j + 1 < m; ++j)
+    for (int j = 0; j < m; ++j)
         if (b[j] == 0.0) {  // breakdown: the leading block is exact
             mm = j + 1;
             break;
         }
-    for (int j = 0; j < mm; ++j) mu += a[j];
-    mu /= mm;
+    const int n = mm < m || b[m - 1] == 0.0 ? mm : m + 1;  // size of the (possibly augmented) system
     for (int j = 0; j < mm; ++j) {
-        a[j] -= mu;
-        const double r = fabs(a[j]) + (j > 0 ? fabs(b[j - 1]) : 0.0) + (j + 1 < mm ? fabs(b[j]) : 0.0);
+        const double r = fabs(a[j]) + (j > 0 ? fabs(b[j - 1]) : 0.0) + fabs(b[j]);
         nrm = r > nrm ? r : nrm;
     }
     int sq = 1;
     while (nrm / sq > 0.5) sq *= 2;
     const double isq = 1.0 / sq;
-    for (int j = 0; j < mm; ++j) g[j] = j == 0 ? 1.0 : 0.0;
-    for (int rep = 0; rep < sq; ++rep) {  // g <- exp(T/sq) g
-        for (int j = 0; j < mm; ++j) {
+    for (int j = 0; j < n; ++j) g[j] = j == 0 ? 1.0 : 0.0;
+    for (int rep = 0; rep < sq; ++rep) {  // g <- exp(M/sq) g
+        for (int j = 0; j < n; ++j) {
             t[j] = g[j];
             f[j] = g[j];
         }
-        for (int k = 1; k <= 24; ++k) {
-            double tn[MAX_ORDER];
+        for (int k = 1; k <= 30; ++k) {
+            double tn[MAX_ORDER + 1];
             double big = 0.0;
-            for (int j = 0; j < mm; ++j) {
-                double v = a[j] * t[j];
-                if (j > 0) v += b[j - 1] * t[j - 1];
-                if (j + 1 < mm) v += b[j] * t[j + 1];
+            for (int j = 0; j < n; ++j) {
+                double v = 0.0;
+                if (j < mm) {
+                    v = a[j] * t[j];
+                    if (j > 0) v += b[j - 1] * t[j - 1];
+                    if (j + 1 < mm) v += b[j] * t[j + 1];
+                } else {
+                    v = b[j - 1] * t[j - 1];  // the augmented row: beta_m e_m^T
+                }
                 tn[j] = v * isq / k;
                 big = fabs(tn[j]) > big ? fabs(tn[j]) : big;
             }
-            for (int j = 0; j < mm; ++j) {
+            for (int j = 0; j < n; ++j) {
                 t[j] = tn[j];
                 f[j] += tn[j];
             }
-            if (big < 1e-18) break;
+            if (big < 1e-19) break;
         }
-        for (int j = 0; j < mm; ++j) g[j] = f[j];
+        for (int j = 0; j < n; ++j) g[j] = f[j];
     }
-    const double e = exp(mu) * S.beta[c];
-    for (int j = 0; j < m; ++j) S.coef[(j + 1) * Dpad + c] = j < mm ? e * g[j] * S.sinv[(j + 1) * Dpad + c] : 0.0;
+    const double e = S.beta[c];
+    for (int j = 0; j <= m; ++j) S.coef[(j + 1) * Dpad + c] = j < n ? e * g[j] * S.sinv[(j + 1) * Dpad + c] : 0.0;
 }
-// y[row,:] = sum_{j=1..m} coef[j][:] * U_j[row,:]  (U_j = Ubase + (j-1)*stride)
+// y[row,:] = sum_{j=1..m+1} coef[j][:] * U_j[row,:]  (U_j = Ubase + (j-1)*stride)
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_lz_combine(int K, int Dpad, int m, const T* __restrict__ Ubase, size_t stride,
                                                       const double* __restrict__ coef, T* __restrict__ Yout,
@@ -548,7 +567,7 @@ __global__ __launch_bounds__(BLOCK) void k_lz_combine(int K, int Dpad, int m, co
     for (size_t o = (size_t)blockIdx.x * BLOCK + threadIdx.x; o < n; o += (size_t)gridDim.x * BLOCK) {
         const int c = (int)(o % Dpad);
         double s = 0.0;
-        for (int j = 1; j <= m; ++j) s += coef[j * Dpad + c] * (double)Ubase[(size_t)(j - 1) * stride + o];
+        for (int j = 1; j <= m + 1; ++j) s += coef[j * Dpad + c] * (double)Ubase[(size_t)(j - 1) * stride + o];
         Yout[o] = (T)s;
     }
 }
@@ -623,15 +642,15 @@ __global__ __launch_bounds__(BLOCK) void k_tracepart(int K, const int* __restric
 }
 
 __host__ __device__ inline int plan_order(int method, double rho, double tol, int max_order) {
-    // smallest m with a remainder bound below tol.  Lanczos (m-dimensional Krylov space): the error is
-    // at most twice the best degree-(m-1) polynomial error on [-rho, rho], bounded by the Chebyshev-shifted
-    // Taylor remainder 2 (rho/2)^m / m! e^{rho};  Taylor degree m: rho^{m+1}/(m+1)! e^{rho}.
+    // smallest m with a remainder bound below tol.  Corrected Lanczos with m steps reproduces polynomials of
+    // degree m: the error is at most twice the best degree-m polynomial error on [-rho, rho], bounded by the
+    // Chebyshev-shifted Taylor remainder 2 (rho/2)^(m+1) / (m+1)! e^{rho};  Taylor degree m: rho^{m+1}/(m+1)! e^{rho}.
     double term = 1.0;
     const double er = exp(2.0 * rho);  // also covers the e^{-rho} lower bound on ||exp(A')b|| / ||b||
     for (int m = 1; m <= max_order; ++m) {
         if (method == 0) {
             term *= (rho * 0.5) / m;
-            if (4.0 * term * er <= tol) return m;
+            if (4.0 * term * (rho * 0.5) / (m + 1) * er <= tol) return m;
         } else {
             term *= rho / m;
             if (term * rho / (m + 1) * er <= tol) return m;

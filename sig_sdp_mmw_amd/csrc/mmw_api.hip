@@ -185,6 +185,12 @@ template <typename T> struct Solver final : mmw_solver {
         hipLaunchKernelGGL((k_sketch_rng<T>), dim3(grid_rows(K)), dim3(BLOCK), 0, st, K, D, eng.lay.Dpad, 99ull, 0u, eng.start_block());
         const bool keep = eng.use_blk;
         eng.use_blk = blocked != 0;
+        DevBuf<unsigned long long> stamps;
+        const bool want_stamps = blocked && getenv("MMW_STAMPS");
+        if (want_stamps) {
+            MMW_TRY(stamps.alloc((size_t)16 * 8192));
+            MMW_HIP(hipMemsetAsync(stamps.p, 0, (size_t)16 * 8192 * sizeof(unsigned long long), st));
+        }
         hipEvent_t e0, e1;
         MMW_HIP(hipEventCreate(&e0));
         MMW_HIP(hipEventCreate(&e1));
@@ -193,6 +199,28 @@ template <typename T> struct Solver final : mmw_solver {
         for (int r = 0; r < reps && rc == MMW_OK; ++r) rc = eng.template launch_spmm<SPMM_PLAIN>(eng.start_block(), eng.Tm.p, nullptr, 0.5, 0.0, 1.0);
         MMW_HIP(hipEventRecord(e1, st));
         MMW_HIP(hipStreamSynchronize(st));
+        if (want_stamps) {
+            g_blk_stamps = stamps.p;
+            rc = eng.template launch_spmm<SPMM_PLAIN>(eng.start_block(), eng.Tm.p, nullptr, 0.5, 0.0, 1.0);
+            g_blk_stamps = nullptr;
+            std::vector<unsigned long long> h((size_t)16 * 8192);
+            MMW_HIP(hipMemcpyAsync(h.data(), stamps.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            MMW_HIP(hipStreamSynchronize(st));
+            double acc[10] = {0};
+            int cnt = 0;
+            unsigned long long tmin = ~0ull, tmax = 0;
+            for (int w = 0; w < 8192; ++w) {
+                const unsigned long long* q = &h[(size_t)w * 16];
+                if (!q[0] || !q[9]) continue;
+                ++cnt;
+                tmin = std::min(tmin, q[0]);
+                tmax = std::max(tmax, q[9]);
+                for (int k = 1; k < 10; ++k) if (q[k] && q[k - 1]) acc[k] += (double)(q[k] - q[k - 1]);
+            }
+            fprintf(stderr, "[stamps] %d workgroups, span %.1f us; mean us per phase:", cnt, (double)(tmax - tmin) * 0.01);
+            for (int k = 1; k < 10; ++k) fprintf(stderr, " p%d=%.2f", k, acc[k] / std::max(cnt, 1) * 0.01);
+            fprintf(stderr, "\n");
+        }
         eng.use_blk = keep;
         float ms = 0;
         MMW_HIP(hipEventElapsedTime(&ms, e0, e1));
