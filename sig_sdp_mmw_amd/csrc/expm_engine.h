@@ -92,6 +92,10 @@ template <typename T> struct ExpmEngine {
     BlkDev blk{};
     const T* val_blk = nullptr;
     int npart = 1;               // partial slabs one SpMM launch writes
+    T* rownorm_d = nullptr;      // optional: the combination also emits ||y_row||^2 and its per-block sums (nblk slabs)
+    double* rownorm_part = nullptr;
+    bool start_colsq_ready = false;  // the producer of the start block already filled `partial` with its column sums of squares (npart_start slabs)
+    int npart_start = 0;
     int kbegin(int slot) { return kt ? kt->begin(slot) : MMW_OK; }
     int kend() { return kt ? kt->end() : MMW_OK; }
 
@@ -214,22 +218,30 @@ template <typename T> struct ExpmEngine {
                 LanczosScalars S = scalars();
                 const int gr = grid_rows(K * 4);  // k_colsq / k_lz_update stride rows by workgroup
                 MMW_TRY(kbegin(KT_KRYLOV_VEC));
-                hipLaunchKernelGGL((k_colsq<T>), dim3(gr), dim3(BLOCK), shcol, st, K, Dpad, U.p, partial.p);
-                MMW_TRY((colreduce<LZ_INIT>(gr, 0, pd)));
+                if (sub == 0 && start_colsq_ready) {
+                    MMW_TRY((colreduce<LZ_INIT>(npart_start, 0, pd)));
+                } else {
+                    hipLaunchKernelGGL((k_colsq<T>), dim3(gr), dim3(BLOCK), shcol, st, K, Dpad, U.p, partial.p);
+                    MMW_TRY((colreduce<LZ_INIT>(gr, 0, pd)));
+                }
+                start_colsq_ready = false;
                 MMW_TRY(kend());
                 for (int j = 1; j <= m; ++j) {
                     MMW_TRY((launch_spmm<SPMM_LANCZOS>(block(j - 1), Tm.p, nullptr, ascale, 0.0, 1.0, pd, j)));
                     MMW_TRY(kbegin(KT_KRYLOV_VEC));
                     MMW_TRY((colreduce<LZ_ALPHA>(npart, j, pd)));
-                    // also for j = m: U_{m+1} = beta_m v_{m+1} feeds the corrected scheme (no further SpMM)
-                    hipLaunchKernelGGL((k_lz_update<T>), dim3(gr), dim3(BLOCK), shcol, st, K, Dpad, j, Tm.p, block(j - 1),
-                                       j > 1 ? block(j - 2) : block(j - 1), block(j), S, partial.p, pd);
-                    MMW_TRY((colreduce<LZ_BETA>(gr, j, pd)));
+                    if (j < m) {  // the last product A U_m goes straight into the combination (corrected scheme)
+                        hipLaunchKernelGGL((k_lz_update<T>), dim3(gr), dim3(BLOCK), shcol, st, K, Dpad, j, Tm.p, block(j - 1),
+                                           j > 1 ? block(j - 2) : block(j - 1), block(j), S, partial.p, pd);
+                        MMW_TRY((colreduce<LZ_BETA>(gr, j, pd)));
+                    }
                     MMW_TRY(kend());
                 }
                 MMW_TRY(kbegin(KT_KRYLOV_VEC));
                 hipLaunchKernelGGL(k_lz_texp, dim3(gcol), dim3(64), 0, st, Dpad, m, 1.0 / nsub, S, pd);
-                hipLaunchKernelGGL((k_lz_combine<T>), dim3(gel), dim3(BLOCK), 0, st, K, Dpad, m, U.p, bs, S.coef, out, pd);
+                const bool last = sub + 1 == nsub;
+                hipLaunchKernelGGL((k_lz_combine<T>), dim3(nblk), dim3(BLOCK), 0, st, K, Dpad, m, U.p, bs, Tm.p, S.coef, out, pd,
+                                   last ? rownorm_d : (T*)nullptr, last ? rownorm_part : (double*)nullptr);
                 MMW_TRY(kend());
             } else {
                 hipLaunchKernelGGL((k_copy<T>), dim3(gel), dim3(BLOCK), 0, st, bs, U.p, out);

@@ -191,7 +191,7 @@ template <typename T> struct Factorizer {
         MMW_HIP(hipStreamSynchronize(st));
         const double rho = *std::max_element(hp.begin(), hp.end());
         // random start block (rows of unit norm; any full-rank start works)
-        hipLaunchKernelGGL((k_sketch_rng<T>), dim3(nblk), dim3(BLOCK), 0, st, K, b, ld, seed ^ 0x9E3779B97F4A7C15ull, 0u, V.p);
+        hipLaunchKernelGGL((k_sketch_rng<T>), dim3(nblk), dim3(BLOCK), 0, st, K, b, ld, seed ^ 0x9E3779B97F4A7C15ull, 0u, V.p, (double*)nullptr);
         MMW_TRY(orthonormalise(b, ld, V, W, 1e-14));
         std::vector<double> theta(b), res(b), hres((size_t)64 * b);
         std::vector<int> perm(b);

@@ -423,7 +423,7 @@ template <int OP>
 __global__ __launch_bounds__(1024) void k_colreduce(int nb, int Dpad, const double* __restrict__ partial, double* __restrict__ out, int j,
                                                     double eps, LanczosScalars S, const ExpmPlan* __restrict__ plan) {
     __shared__ double sh[16][64];
-    if (plan && OP != LZ_INIT && OP != LZ_NONE && j > plan->m) return;
+    if (plan && ((OP == LZ_ALPHA && j > plan->m) || (OP == LZ_BETA && j >= plan->m))) return;
     const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     double s = 0.0;
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(BLOCK) void k_lz_update(int K, int Dpad, int j, con
                                                      const T* __restrict__ Ujm1, T* __restrict__ Unext, LanczosScalars S,
                                                      double* __restrict__ partial, const ExpmPlan* __restrict__ plan) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    if (plan && j > plan->m) return;  // steps beyond the planned order
+    if (plan && j >= plan->m) return;  // U_{m+1} is never formed: the last product feeds the combination directly
     double* sh = reinterpret_cast<double*>(smem_raw);  // [BLOCK]
     const int rpp = BLOCK / Dpad > 0 ? BLOCK / Dpad : 1;
     for (int c0 = 0; c0 < Dpad; c0 += BLOCK) {
@@ -492,12 +492,14 @@ __global__ __launch_bounds__(BLOCK) void k_lz_update(int K, int Dpad, int j, con
     }
 }
 // per column: the corrected Krylov approximation (Saad 1992) of exp(A/nsub) b from m Lanczos steps:
-//   y = beta0 * [ V_m exp(T_m) e_1 + beta_m (e_m^T phi_1(T_m) e_1) v_{m+1} ],
-// i.e. the first column of exp of the (m+1) x (m+1) augmented matrix [[T_m, 0], [beta_m e_m^T, 0]].
-// It spends the direction A v_m that the m-th SpMM produced anyway, which buys one polynomial degree:
-// m SpMMs reach the accuracy of a degree-m Taylor polynomial.  coef[j] = beta0 * g_j * sinv_j, j = 1..m+1.
-// exp(M) e_1 by a scaled Taylor series on the small vector (||M|| is tiny here; repeated application keeps it
-// valid for any norm).
+//   y = beta0 * [ V_m exp(T) e_1 + (1/nsub) phi * w ],   T = T_m/nsub,  phi = e_m^T phi_1(T) e_1,
+//   w = A v_m - alpha_m v_m - beta_{m-1} v_{m-1}  (= beta_m v_{m+1}; never formed, never normalised),
+// [exp(T) e_1; phi] being the first column of exp of the augmented matrix [[T, 0], [e_m^T, 0]].
+// It spends the product A v_m that the m-th SpMM made anyway, which buys one polynomial degree: m SpMMs
+// reach the accuracy of a degree-m Taylor polynomial.  Output, so that y = sum_{j<=m} coef[j] U_j + coef[m+1] * t_m
+// with t_m = A U_m (the last SpMM's output, U_j unnormalised):
+//   coef[j] = beta0 g_j sinv_j  minus the w-terms folded onto U_m and U_{m-1};  coef[m+1] = beta0 phi sinv_m / nsub.
+// exp(M) e_1 by a scaled Taylor series on the small vector (repeated application keeps it valid for any norm).
 __global__ void k_lz_texp(int Dpad, int m, double inv_nsub, LanczosScalars S, const ExpmPlan* __restrict__ plan) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= Dpad) return;
@@ -510,18 +512,20 @@ __global__ void k_lz_texp(int Dpad, int m, double inv_nsub, LanczosScalars S, co
     int mm = m;  // Krylov dimension actually reached
     for (int j = 0; j < m; ++j) {
         a[j] = S.alpha[(j + 1) * Dpad + c] * inv_nsub;
-        b[j] = S.beta[(j + 1) * Dpad + c] * inv_nsub;  // b[j] couples j and j+1; b[m-1] = beta_m feeds the correction
+        b[j] = j + 1 < m ? S.beta[(j + 1) * Dpad + c] * inv_nsub : 0.0;  // b[j] couples j and j+1
     }
-    for (int j = 0; j < m; ++j)
-        if (b[j] == 0.0) {  // breakdown: the leading block is exact
+    for (int j = 0; j + 1 < m; ++j)
+        if (b[j] == 0.0) {  // breakdown: the leading block is exact and there is no correction
             mm = j + 1;
             break;
         }
-    const int n = mm < m || b[m - 1] == 0.0 ? mm : m + 1;  // size of the (possibly augmented) system
+    const bool corrected = mm == m && S.sinv[m * Dpad + c] != 0.0;
+    const int n = corrected ? m + 1 : mm;
     for (int j = 0; j < mm; ++j) {
-        const double r = fabs(a[j]) + (j > 0 ? fabs(b[j - 1]) : 0.0) + fabs(b[j]);
+        const double r = fabs(a[j]) + (j > 0 ? fabs(b[j - 1]) : 0.0) + (j + 1 < mm ? fabs(b[j]) : 0.0);
         nrm = r > nrm ? r : nrm;
     }
+    if (corrected && nrm < 1.0) nrm = 1.0;  // the augmented row e_m^T
     int sq = 1;
     while (nrm / sq > 0.5) sq *= 2;
     const double isq = 1.0 / sq;
@@ -541,7 +545,7 @@ __global__ void k_lz_texp(int Dpad, int m, double inv_nsub, LanczosScalars S, co
                     if (j > 0) v += b[j - 1] * t[j - 1];
                     if (j + 1 < mm) v += b[j] * t[j + 1];
                 } else {
-                    v = b[j - 1] * t[j - 1];  // the augmented row: beta_m e_m^T
+                    v = t[j - 1];  // the augmented row e_m^T
                 }
                 tn[j] = v * isq / k;
                 big = fabs(tn[j]) > big ? fabs(tn[j]) : big;
@@ -555,20 +559,49 @@ __global__ void k_lz_texp(int Dpad, int m, double inv_nsub, LanczosScalars S, co
         for (int j = 0; j < n; ++j) g[j] = f[j];
     }
     const double e = S.beta[c];
-    for (int j = 0; j <= m; ++j) S.coef[(j + 1) * Dpad + c] = j < n ? e * g[j] * S.sinv[(j + 1) * Dpad + c] : 0.0;
+    for (int j = 0; j < m; ++j) S.coef[(j + 1) * Dpad + c] = j < mm ? e * g[j] * S.sinv[(j + 1) * Dpad + c] : 0.0;
+    double ct = 0.0;
+    if (corrected) {
+        const double sm = S.sinv[m * Dpad + c];
+        const double w = e * g[m] * inv_nsub;  // weight of w = sm*t_m - alpha_m sm U_m - beta_{m-1} s_{m-1} U_{m-1}
+        ct = w * sm;
+        S.coef[m * Dpad + c] -= w * S.alpha[m * Dpad + c] * sm;
+        if (m > 1) S.coef[(m - 1) * Dpad + c] -= w * S.beta[(m - 1) * Dpad + c] * S.sinv[(m - 1) * Dpad + c];
+    }
+    S.coef[(m + 1) * Dpad + c] = ct;
 }
-// y[row,:] = sum_{j=1..m+1} coef[j][:] * U_j[row,:]  (U_j = Ubase + (j-1)*stride)
+// y[row,:] = sum_{j=1..m} coef[j][:] * U_j[row,:] + coef[m+1][:] * Tm[row,:]   (U_j = Ubase + (j-1)*stride),
+// one wavefront per row; optionally also d[row] = ||y_row||^2 and per-block partial sums of d (the trace).
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_lz_combine(int K, int Dpad, int m, const T* __restrict__ Ubase, size_t stride,
-                                                      const double* __restrict__ coef, T* __restrict__ Yout,
-                                                      const ExpmPlan* __restrict__ plan) {
+                                                      const T* __restrict__ Tm, const double* __restrict__ coef, T* __restrict__ Yout,
+                                                      const ExpmPlan* __restrict__ plan, T* __restrict__ d,
+                                                      double* __restrict__ dpart) {
+    __shared__ double sh[WAVES_PER_BLOCK];
     if (plan) m = plan->m;
-    const size_t n = (size_t)K * Dpad;
-    for (size_t o = (size_t)blockIdx.x * BLOCK + threadIdx.x; o < n; o += (size_t)gridDim.x * BLOCK) {
-        const int c = (int)(o % Dpad);
-        double s = 0.0;
-        for (int j = 1; j <= m + 1; ++j) s += coef[j * Dpad + c] * (double)Ubase[(size_t)(j - 1) * stride + o];
-        Yout[o] = (T)s;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    double tot = 0.0;
+    for (int row = blockIdx.x * WAVES_PER_BLOCK + wib; row < K; row += gridDim.x * WAVES_PER_BLOCK) {
+        double ss = 0.0;
+        for (int c = lane; c < Dpad; c += WAVE) {
+            const size_t o = (size_t)row * Dpad + c;
+            double s = coef[(m + 1) * Dpad + c] * (double)Tm[o];
+            for (int j = 1; j <= m; ++j) s += coef[j * Dpad + c] * (double)Ubase[(size_t)(j - 1) * stride + o];
+            const T y = (T)s;
+            Yout[o] = y;
+            ss += (double)y * (double)y;
+        }
+        if (d) {
+            ss = wave_sum(ss);
+            if (lane == 0) {
+                d[row] = (T)ss;
+                tot += (double)(T)ss;
+            }
+        }
+    }
+    if (d) {
+        tot = block_sum(tot, sh);
+        if (threadIdx.x == 0) dpart[blockIdx.x] = tot;
     }
 }
 // y *= scale (Taylor: e^{mu})

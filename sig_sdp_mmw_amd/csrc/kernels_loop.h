@@ -411,11 +411,19 @@ __device__ __forceinline__ void normals16(const uint32_t (&w)[4], float (&n)[4])
 __device__ __forceinline__ void normals16(const uint32_t (&w)[4], double (&n)[2]) { box_muller(w, n[0], n[1]); }
 
 template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_sketch_rng(int K, int D, int Dpad, uint64_t seed, uint32_t iter, T* __restrict__ R) {
+__global__ __launch_bounds__(BLOCK) void k_sketch_rng(int K, int D, int Dpad, uint64_t seed, uint32_t iter, T* __restrict__ R,
+                                                      double* __restrict__ colsq_part) {
     constexpr int VEC = V16<T>::N;
     constexpr int NS = 4;  // 64 lanes x 4 steps x 16 B covers Dpad <= 1024 floats / 512 doubles
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* shc = reinterpret_cast<double*>(smem_raw);  // [WAVES_PER_BLOCK][Dpad] when colsq_part
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int ngroups = Dpad / VEC;
+    double csq[NS][VEC];
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) csq[i][v] = 0.0;
     for (int row = blockIdx.x * WAVES_PER_BLOCK + wib; row < K; row += gridDim.x * WAVES_PER_BLOCK) {
         T n[NS][VEC];
         double ss = 0.0;
@@ -442,9 +450,27 @@ __global__ __launch_bounds__(BLOCK) void k_sketch_rng(int K, int D, int Dpad, ui
             const int p = lane + WAVE * i;
             if (p < ngroups) {
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) n[i][v] *= inv;
+                for (int v = 0; v < VEC; ++v) {
+                    n[i][v] *= inv;
+                    csq[i][v] += (double)n[i][v] * (double)n[i][v];
+                }
                 store16(R + (size_t)row * Dpad + (size_t)p * VEC, n[i]);
             }
+        }
+    }
+    if (colsq_part) {  // column sums of squares of this block's rows: the Lanczos start norms come for free
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int p = lane + WAVE * i;
+            if (p < ngroups)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) shc[wib * Dpad + p * VEC + v] = csq[i][v];
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < Dpad; c += BLOCK) {
+            double t = 0.0;
+            for (int w = 0; w < WAVES_PER_BLOCK; ++w) t += shc[w * Dpad + c];
+            colsq_part[(size_t)blockIdx.x * Dpad + c] = t;
         }
     }
 }

@@ -182,7 +182,7 @@ template <typename T> struct Solver final : mmw_solver {
         MMW_HIP(hipSetDevice(device));
         if (blocked && !HB.usable) return fail(MMW_ERR_STATE, "no locality blocking for this pattern");
         MMW_TRY(sync());
-        hipLaunchKernelGGL((k_sketch_rng<T>), dim3(grid_rows(K)), dim3(BLOCK), 0, st, K, D, eng.lay.Dpad, 99ull, 0u, eng.start_block());
+        hipLaunchKernelGGL((k_sketch_rng<T>), dim3(grid_rows(K)), dim3(BLOCK), 0, st, K, D, eng.lay.Dpad, 99ull, 0u, eng.start_block(), (double*)nullptr);
         const bool keep = eng.use_blk;
         eng.use_blk = blocked != 0;
         DevBuf<unsigned long long> stamps;
@@ -371,15 +371,22 @@ template <typename T> struct Solver final : mmw_solver {
                 hipLaunchKernelGGL((k_import_block<T>), dim3(grid_elems(eng.bs)), dim3(BLOCK), 0, st, K, D, Dpad, stage64.p, eng.start_block());
                 last_was_rng = false;
             } else {
-                hipLaunchKernelGGL((k_sketch_rng<T>), dim3(gr), dim3(BLOCK), 0, st, K, D, Dpad, seed, (uint32_t)iter, eng.start_block());
+                const bool lz = eng.method == MMW_EXPM_LANCZOS;
+                hipLaunchKernelGGL((k_sketch_rng<T>), dim3(gr), dim3(BLOCK), lz ? (size_t)WAVES_PER_BLOCK * Dpad * sizeof(double) : 0, st, K, D, Dpad,
+                                   seed, (uint32_t)iter, eng.start_block(), lz ? eng.partial.p : (double*)nullptr);
+                eng.start_colsq_ready = lz;  // the Lanczos start norms come out of the sketch kernel
+                eng.npart_start = gr;
                 last_was_rng = true;
                 last_seed = seed;
             }
             MMW_TRY(kt.end());
             MMW_HIP(hipGetLastError());
+            eng.rownorm_d = drow.p;  // the Lanczos combination also emits the row norms and the trace slabs
+            eng.rownorm_part = tr_part.p;
             MMW_TRY(eng.apply(Xh.p, 0.5, trace_part.p, gr, m_launch));
             MMW_TRY(kt.begin(KT_SDDMM));
-            hipLaunchKernelGGL((k_rownorm2<T>), dim3(gr), dim3(BLOCK), 0, st, K, Dpad, Xh.p, drow.p, tr_part.p);
+            if (eng.method != MMW_EXPM_LANCZOS)
+                hipLaunchKernelGGL((k_rownorm2<T>), dim3(gr), dim3(BLOCK), 0, st, K, Dpad, Xh.p, drow.p, tr_part.p);
             if (sddmm_blk && eng.use_blk) {
                 SdDev S;
                 S.ptr = b_sdptr.p; S.la = b_sdla.p; S.lb = b_sdlb.p; S.epos = b_sdepos.p;
@@ -456,7 +463,7 @@ template <typename T> struct Solver final : mmw_solver {
             case MMW_F_XHALF: return export_block(Xh.p, out, n);
             case MMW_F_SKETCH: {
                 if (!last_was_rng || iter == 0) return fail(MMW_ERR_STATE, "the sketch can be read back only after a device-generated iteration");
-                hipLaunchKernelGGL((k_sketch_rng<T>), dim3(grid_rows(K)), dim3(BLOCK), 0, st, K, D, eng.lay.Dpad, last_seed, (uint32_t)(iter - 1), eng.Tm.p);
+                hipLaunchKernelGGL((k_sketch_rng<T>), dim3(grid_rows(K)), dim3(BLOCK), 0, st, K, D, eng.lay.Dpad, last_seed, (uint32_t)(iter - 1), eng.Tm.p, (double*)nullptr);
                 return export_block(eng.Tm.p, out, n);
             }
             case MMW_F_S_SUM: return export_host(H.S_sum, out, n);

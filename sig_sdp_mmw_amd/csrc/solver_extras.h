@@ -90,7 +90,7 @@ template <typename T> struct Extras {
         auto blk = [&](int j) { return g_vec.p + (size_t)((j - 1) % 3) * bs; };
         const double eps = sizeof(T) == 4 ? 1e-6 : 1e-14;
         // deterministic start vector: Philox normals, one column
-        hipLaunchKernelGGL((k_sketch_rng<T>), dim3(nblk), dim3(BLOCK), 0, st, K, 1, Dp, 0x6a09e667f3bcc908ull, 7u, blk(1));
+        hipLaunchKernelGGL((k_sketch_rng<T>), dim3(nblk), dim3(BLOCK), 0, st, K, 1, Dp, 0x6a09e667f3bcc908ull, 7u, blk(1), (double*)nullptr);
         // rows are normalised to +-1 by the sketch kernel; that is a fine start vector
         hipLaunchKernelGGL((k_colsq<T>), dim3(gr), dim3(BLOCK), shcol, st, K, Dp, blk(1), part.p);
         hipLaunchKernelGGL((k_colreduce<LZ_INIT>), dim3((Dp + 63) / 64), dim3(1024), 0, st, gr, Dp, part.p, g_colsum.p, 0, eps, S, (const ExpmPlan*)nullptr);
