@@ -158,7 +158,7 @@ template <typename T> struct ExpmEngine {
     }
     template <int OP> int colreduce(int nb, int j, const ExpmPlan* plan) {
         const double eps = sizeof(T) == 4 ? 1e-6 : 1e-14;
-        hipLaunchKernelGGL((k_colreduce<OP>), dim3((lay.Dpad + 63) / 64), dim3(1024), 0, st, nb, lay.Dpad, partial.p, colsum.p, j, eps, scalars(), plan);
+        hipLaunchKernelGGL((k_colreduce<OP>), dim3((lay.Dpad + 15) / 16), dim3(1024), 0, st, nb, lay.Dpad, partial.p, colsum.p, j, eps, scalars(), plan);
         MMW_HIP(hipGetLastError());
         return MMW_OK;
     }

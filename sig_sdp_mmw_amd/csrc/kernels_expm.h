@@ -407,8 +407,8 @@ __global__ __launch_bounds__(BLOCK) void k_colsq(int K, int Dpad, const T* __res
     }
 }
 
-// out[col] = sum_b partial[b][col] in a fixed order: one workgroup per 64 columns, 16 row slices per column,
-// reads coalesced across columns.  The Lanczos scalar update that consumes the sum is fused in (OP).
+// out[col] = sum_b partial[b][col] in a fixed order: one workgroup per 16 columns (128-byte row segments), 64 row
+// slices per column.  The Lanczos scalar update that consumes the sum is fused in (OP).
 enum { LZ_NONE = 0, LZ_INIT = 1, LZ_ALPHA = 2, LZ_BETA = 3 };
 // Lanczos scalars, per column c (all arrays [MAX_ORDER+2][Dpad], index j = Lanczos step starting at 1):
 //   beta[0] = ||b_c||, sinv[j] = 1/beta[j-1] (0 when the Krylov space is exhausted), alpha[j].
@@ -422,19 +422,19 @@ struct LanczosScalars {
 template <int OP>
 __global__ __launch_bounds__(1024) void k_colreduce(int nb, int Dpad, const double* __restrict__ partial, double* __restrict__ out, int j,
                                                     double eps, LanczosScalars S, const ExpmPlan* __restrict__ plan) {
-    __shared__ double sh[16][64];
+    __shared__ double sh[64][17];
     if (plan && ((OP == LZ_ALPHA && j > plan->m) || (OP == LZ_BETA && j >= plan->m))) return;
-    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double s = 0.0;
     if (c < Dpad)
-        for (int b = sl; b < nb; b += 16) s += partial[(size_t)b * Dpad + c];
+        for (int b = sl; b < nb; b += 64) s += partial[(size_t)b * Dpad + c];
     sh[sl][cl] = s;
     __syncthreads();
     if (sl == 0 && c < Dpad) {
         double t = 0.0;
 #pragma unroll
-        for (int p = 0; p < 16; ++p) t += sh[p][cl];
+        for (int p = 0; p < 64; ++p) t += sh[p][cl];
         if (OP == LZ_NONE) {
             out[c] = t;
         } else if (OP == LZ_INIT) {  // beta0 = ||b_c||, sinv1
@@ -500,6 +500,82 @@ __global__ __launch_bounds__(BLOCK) void k_lz_update(int K, int Dpad, int j, con
 // with t_m = A U_m (the last SpMM's output, U_j unnormalised):
 //   coef[j] = beta0 g_j sinv_j  minus the w-terms folded onto U_m and U_{m-1};  coef[m+1] = beta0 phi sinv_m / nsub.
 // exp(M) e_1 by a scaled Taylor series on the small vector (repeated application keeps it valid for any norm).
+template <int NMAX>  // NMAX >= m + 1; all loops fully unrolled so the small vectors live in registers
+__device__ __forceinline__ void texp_core(int Dpad, int c, int m, double inv_nsub, LanczosScalars S) {
+    double a[NMAX], b[NMAX], g[NMAX], t[NMAX], f[NMAX];
+    double nrm = 0.0;
+    int mm = m;  // Krylov dimension actually reached
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) {
+        a[j] = j < m ? S.alpha[(j + 1) * Dpad + c] * inv_nsub : 0.0;
+        b[j] = j + 1 < m ? S.beta[(j + 1) * Dpad + c] * inv_nsub : 0.0;  // b[j] couples j and j+1
+    }
+#pragma unroll
+    for (int j = NMAX - 1; j >= 0; --j)
+        if (j + 1 < m && b[j] == 0.0) mm = j + 1;  // breakdown: the leading block is exact, no correction
+    const bool corrected = mm == m && S.sinv[m * Dpad + c] != 0.0;
+    const int n = corrected ? m + 1 : mm;
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j)
+        if (j < mm) {
+            const double r = fabs(a[j]) + (j > 0 ? fabs(b[j > 0 ? j - 1 : 0]) : 0.0) + (j + 1 < mm ? fabs(b[j]) : 0.0);
+            nrm = r > nrm ? r : nrm;
+        }
+    if (corrected && nrm < 1.0) nrm = 1.0;  // the augmented row e_m^T
+    int sq = 1;
+    while (nrm / sq > 0.5) sq *= 2;
+    const double isq = 1.0 / sq;
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) g[j] = j == 0 ? 1.0 : 0.0;
+    for (int rep = 0; rep < sq; ++rep) {  // g <- exp(M/sq) g
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) {
+            t[j] = g[j];
+            f[j] = g[j];
+        }
+        for (int k = 1; k <= 30; ++k) {
+            double tn[NMAX];
+            double big = 0.0;
+#pragma unroll
+            for (int j = 0; j < NMAX; ++j) {
+                double v = 0.0;
+                if (j < mm) {
+                    v = a[j] * t[j];
+                    if (j > 0) v += b[j > 0 ? j - 1 : 0] * t[j > 0 ? j - 1 : 0];
+                    if (j + 1 < mm && j + 1 < NMAX) v += b[j] * t[j + 1 < NMAX ? j + 1 : j];
+                } else if (j < n) {
+                    v = t[j > 0 ? j - 1 : 0];  // the augmented row e_m^T
+                }
+                tn[j] = v * isq / k;
+                big = fabs(tn[j]) > big ? fabs(tn[j]) : big;
+            }
+#pragma unroll
+            for (int j = 0; j < NMAX; ++j) {
+                t[j] = tn[j];
+                f[j] += tn[j];
+            }
+            if (big < 1e-19) break;
+        }
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) g[j] = f[j];
+    }
+    const double e = S.beta[c];
+    double gm = 0.0;
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) {
+        if (j < m) S.coef[(j + 1) * Dpad + c] = j < mm ? e * g[j] * S.sinv[(j + 1) * Dpad + c] : 0.0;
+        if (j == m) gm = g[j];
+    }
+    double ct = 0.0;
+    if (corrected) {
+        const double sm = S.sinv[m * Dpad + c];
+        const double w = e * gm * inv_nsub;  // weight of w = sm*t_m - alpha_m sm U_m - beta_{m-1} s_{m-1} U_{m-1}
+        ct = w * sm;
+        S.coef[m * Dpad + c] -= w * S.alpha[m * Dpad + c] * sm;
+        if (m > 1) S.coef[(m - 1) * Dpad + c] -= w * S.beta[(m - 1) * Dpad + c] * S.sinv[(m - 1) * Dpad + c];
+    }
+    S.coef[(m + 1) * Dpad + c] = ct;
+}
 __global__ void k_lz_texp(int Dpad, int m, double inv_nsub, LanczosScalars S, const ExpmPlan* __restrict__ plan) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= Dpad) return;
@@ -507,68 +583,9 @@ __global__ void k_lz_texp(int Dpad, int m, double inv_nsub, LanczosScalars S, co
         m = plan->m;
         inv_nsub = 1.0 / plan->nsub;
     }
-    double a[MAX_ORDER + 1], b[MAX_ORDER + 1], g[MAX_ORDER + 1], t[MAX_ORDER + 1], f[MAX_ORDER + 1];
-    double nrm = 0.0;
-    int mm = m;  // Krylov dimension actually reached
-    for (int j = 0; j < m; ++j) {
-        a[j] = S.alpha[(j + 1) * Dpad + c] * inv_nsub;
-        b[j] = j + 1 < m ? S.beta[(j + 1) * Dpad + c] * inv_nsub : 0.0;  // b[j] couples j and j+1
-    }
-    for (int j = 0; j + 1 < m; ++j)
-        if (b[j] == 0.0) {  // breakdown: the leading block is exact and there is no correction
-            mm = j + 1;
-            break;
-        }
-    const bool corrected = mm == m && S.sinv[m * Dpad + c] != 0.0;
-    const int n = corrected ? m + 1 : mm;
-    for (int j = 0; j < mm; ++j) {
-        const double r = fabs(a[j]) + (j > 0 ? fabs(b[j - 1]) : 0.0) + (j + 1 < mm ? fabs(b[j]) : 0.0);
-        nrm = r > nrm ? r : nrm;
-    }
-    if (corrected && nrm < 1.0) nrm = 1.0;  // the augmented row e_m^T
-    int sq = 1;
-    while (nrm / sq > 0.5) sq *= 2;
-    const double isq = 1.0 / sq;
-    for (int j = 0; j < n; ++j) g[j] = j == 0 ? 1.0 : 0.0;
-    for (int rep = 0; rep < sq; ++rep) {  // g <- exp(M/sq) g
-        for (int j = 0; j < n; ++j) {
-            t[j] = g[j];
-            f[j] = g[j];
-        }
-        for (int k = 1; k <= 30; ++k) {
-            double tn[MAX_ORDER + 1];
-            double big = 0.0;
-            for (int j = 0; j < n; ++j) {
-                double v = 0.0;
-                if (j < mm) {
-                    v = a[j] * t[j];
-                    if (j > 0) v += b[j - 1] * t[j - 1];
-                    if (j + 1 < mm) v += b[j] * t[j + 1];
-                } else {
-                    v = t[j - 1];  // the augmented row e_m^T
-                }
-                tn[j] = v * isq / k;
-                big = fabs(tn[j]) > big ? fabs(tn[j]) : big;
-            }
-            for (int j = 0; j < n; ++j) {
-                t[j] = tn[j];
-                f[j] += tn[j];
-            }
-            if (big < 1e-19) break;
-        }
-        for (int j = 0; j < n; ++j) g[j] = f[j];
-    }
-    const double e = S.beta[c];
-    for (int j = 0; j < m; ++j) S.coef[(j + 1) * Dpad + c] = j < mm ? e * g[j] * S.sinv[(j + 1) * Dpad + c] : 0.0;
-    double ct = 0.0;
-    if (corrected) {
-        const double sm = S.sinv[m * Dpad + c];
-        const double w = e * g[m] * inv_nsub;  // weight of w = sm*t_m - alpha_m sm U_m - beta_{m-1} s_{m-1} U_{m-1}
-        ct = w * sm;
-        S.coef[m * Dpad + c] -= w * S.alpha[m * Dpad + c] * sm;
-        if (m > 1) S.coef[(m - 1) * Dpad + c] -= w * S.beta[(m - 1) * Dpad + c] * S.sinv[(m - 1) * Dpad + c];
-    }
-    S.coef[(m + 1) * Dpad + c] = ct;
+    if (m + 1 <= 4) texp_core<4>(Dpad, c, m, inv_nsub, S);
+    else if (m + 1 <= 8) texp_core<8>(Dpad, c, m, inv_nsub, S);
+    else texp_core<MAX_ORDER + 1>(Dpad, c, m, inv_nsub, S);
 }
 // y[row,:] = sum_{j=1..m} coef[j][:] * U_j[row,:] + coef[m+1][:] * Tm[row,:]   (U_j = Ubase + (j-1)*stride),
 // one wavefront per row; optionally also d[row] = ||y_row||^2 and per-block partial sums of d (the trace).
@@ -577,19 +594,32 @@ __global__ __launch_bounds__(BLOCK) void k_lz_combine(int K, int Dpad, int m, co
                                                       const T* __restrict__ Tm, const double* __restrict__ coef, T* __restrict__ Yout,
                                                       const ExpmPlan* __restrict__ plan, T* __restrict__ d,
                                                       double* __restrict__ dpart) {
+    constexpr int VEC = V16<T>::N;
     __shared__ double sh[WAVES_PER_BLOCK];
     if (plan) m = plan->m;
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int ngroups = Dpad / VEC;
     double tot = 0.0;
     for (int row = blockIdx.x * WAVES_PER_BLOCK + wib; row < K; row += gridDim.x * WAVES_PER_BLOCK) {
         double ss = 0.0;
-        for (int c = lane; c < Dpad; c += WAVE) {
-            const size_t o = (size_t)row * Dpad + c;
-            double s = coef[(m + 1) * Dpad + c] * (double)Tm[o];
-            for (int j = 1; j <= m; ++j) s += coef[j * Dpad + c] * (double)Ubase[(size_t)(j - 1) * stride + o];
-            const T y = (T)s;
-            Yout[o] = y;
-            ss += (double)y * (double)y;
+        for (int p = lane; p < ngroups; p += WAVE) {
+            const size_t o = (size_t)row * Dpad + (size_t)p * VEC;
+            T x[VEC];
+            double s[VEC];
+            load16(Tm + o, x);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) s[v] = coef[(m + 1) * Dpad + p * VEC + v] * (double)x[v];
+            for (int j = 1; j <= m; ++j) {
+                load16(Ubase + (size_t)(j - 1) * stride + o, x);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) s[v] += coef[j * Dpad + p * VEC + v] * (double)x[v];
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                x[v] = (T)s[v];
+                ss += (double)x[v] * (double)x[v];
+            }
+            store16(Yout + o, x);
         }
         if (d) {
             ss = wave_sum(ss);

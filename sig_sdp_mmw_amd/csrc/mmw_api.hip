@@ -326,7 +326,7 @@ template <typename T> struct Solver final : mmw_solver {
         if (n < 0) return fail(MMW_ERR_ARG, "n must be >= 0");
         MMW_TRY(settle());
         if (iter + n > nit) return fail(MMW_ERR_STATE, "mmw_iterate: more iterations than announced to mmw_create/mmw_reset");
-        const bool optimistic = randv == nullptr && n > 1 && !getenv("MMW_SYNC_PLAN");
+        const bool optimistic = randv == nullptr && n > 1 && !kt.on && !getenv("MMW_SYNC_PLAN");  // profiling counts exact launches
         if (optimistic) {
             MMW_TRY(copy_state(true));
             pend_iter0 = iter; pend_n = n; pend_seed = seed;
@@ -372,10 +372,11 @@ template <typename T> struct Solver final : mmw_solver {
                 last_was_rng = false;
             } else {
                 const bool lz = eng.method == MMW_EXPM_LANCZOS;
-                hipLaunchKernelGGL((k_sketch_rng<T>), dim3(gr), dim3(BLOCK), lz ? (size_t)WAVES_PER_BLOCK * Dpad * sizeof(double) : 0, st, K, D, Dpad,
+                const int gs = std::min(gr, 256);  // few slabs for the start-norm reduction
+                hipLaunchKernelGGL((k_sketch_rng<T>), dim3(gs), dim3(BLOCK), lz ? (size_t)WAVES_PER_BLOCK * Dpad * sizeof(double) : 0, st, K, D, Dpad,
                                    seed, (uint32_t)iter, eng.start_block(), lz ? eng.partial.p : (double*)nullptr);
                 eng.start_colsq_ready = lz;  // the Lanczos start norms come out of the sketch kernel
-                eng.npart_start = gr;
+                eng.npart_start = gs;
                 last_was_rng = true;
                 last_seed = seed;
             }

@@ -93,7 +93,7 @@ template <typename T> struct Extras {
         hipLaunchKernelGGL((k_sketch_rng<T>), dim3(nblk), dim3(BLOCK), 0, st, K, 1, Dp, 0x6a09e667f3bcc908ull, 7u, blk(1), (double*)nullptr);
         // rows are normalised to +-1 by the sketch kernel; that is a fine start vector
         hipLaunchKernelGGL((k_colsq<T>), dim3(gr), dim3(BLOCK), shcol, st, K, Dp, blk(1), part.p);
-        hipLaunchKernelGGL((k_colreduce<LZ_INIT>), dim3((Dp + 63) / 64), dim3(1024), 0, st, gr, Dp, part.p, g_colsum.p, 0, eps, S, (const ExpmPlan*)nullptr);
+        hipLaunchKernelGGL((k_colreduce<LZ_INIT>), dim3((Dp + 15) / 16), dim3(1024), 0, st, gr, Dp, part.p, g_colsum.p, 0, eps, S, (const ExpmPlan*)nullptr);
         std::vector<double> a, b, ha((size_t)(m_max + 3) * Dp), hb((size_t)(m_max + 3) * Dp);
         const double tol = sizeof(T) == 4 ? 1e-5 : 1e-11;
         double theta = 0.0;
@@ -102,9 +102,9 @@ template <typename T> struct Extras {
             const int jend = std::min(m_max, j + chunk - 1);
             for (; j <= jend; ++j) {
                 MMW_TRY((spmm_launch<T, SPMM_LANCZOS>(st, K, lay, nblk, indptr, col, val, blk(j), g_tm.p, nullptr, nullptr, 1.0, 0.0, 1.0, part.p)));
-                hipLaunchKernelGGL((k_colreduce<LZ_ALPHA>), dim3((Dp + 63) / 64), dim3(1024), 0, st, nblk, Dp, part.p, g_colsum.p, j, eps, S, (const ExpmPlan*)nullptr);
+                hipLaunchKernelGGL((k_colreduce<LZ_ALPHA>), dim3((Dp + 15) / 16), dim3(1024), 0, st, nblk, Dp, part.p, g_colsum.p, j, eps, S, (const ExpmPlan*)nullptr);
                 hipLaunchKernelGGL((k_lz_update<T>), dim3(gr), dim3(BLOCK), shcol, st, K, Dp, j, g_tm.p, blk(j), j > 1 ? blk(j - 1) : blk(j), blk(j + 1), S, part.p, (const ExpmPlan*)nullptr);
-                hipLaunchKernelGGL((k_colreduce<LZ_BETA>), dim3((Dp + 63) / 64), dim3(1024), 0, st, gr, Dp, part.p, g_colsum.p, j, eps, S, (const ExpmPlan*)nullptr);
+                hipLaunchKernelGGL((k_colreduce<LZ_BETA>), dim3((Dp + 15) / 16), dim3(1024), 0, st, gr, Dp, part.p, g_colsum.p, j, eps, S, (const ExpmPlan*)nullptr);
             }
             MMW_HIP(hipGetLastError());
             const int m = j - 1;
