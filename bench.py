@@ -144,8 +144,17 @@ def main():
     b_spmm = nnzL * (w + 4) + (K + 1) * 4 + 2 * K * D * w
     spmm_avg_us = spmm_us / max(spmm_n, 1)
     achieved = b_spmm / (spmm_avg_us * 1e-6) / 1e9 if spmm_n else 0.0
+    traffic = None  # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/)
+    for fn in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+        if fn.endswith(".json") and "pmc_traffic" in fn:
+            try:
+                rec = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                if rec.get("workload") == args.workload and dtype_name == "f32" and args.expm == "lanczos":
+                    traffic = rec["traffic_bytes_per_launch"]
+            except Exception:
+                pass
     roofline = {"bound": "hbm", "kernel": "k_spmm (CSR SpMM of the Lanczos/Taylor step)", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "bytes_per_launch": int(b_spmm), "avg_launch_us": round(spmm_avg_us, 2), "launches": int(spmm_n),
                 "launches_per_step": round(spmm_n / max(args.steps, 1), 2)}
     phases = {k: round(v[0] / max(args.steps, 1), 2) for k, v in kt.items() if v[1]}
@@ -164,12 +173,14 @@ def main():
     # ---- CPU baseline: the oracle on this host, bounded sample of the same instance (rank 0, N = 1 only)
     if rank == 0 and world == 1 and args.cpu_iters != 0:
         from oracle import mmw_oracle as orc
-        iters = args.cpu_iters
-        if iters < 0:
-            iters = 2 if nnzL * D > 2e8 else (5 if nnzL * D > 2e7 else 20)
-        o = orc.MMWOracle(nit=iters, eta=args.eta)
         rng = np.random.RandomState(0)
         pat = orc.Pattern(Z, state)  # one-off state processing, outside the timed sample like on the GPU side
+        iters = args.cpu_iters
+        if iters < 0:  # size the sample to ~15 s of CPU work from one probe iteration
+            p0 = time.perf_counter()
+            orc.MMWOracle(nit=1, eta=args.eta).run(Z, state, lambda i, K_, D_: orc.sketch_rows(rng.randn(K_, D_)), factor=False, pattern=pat)
+            iters = int(min(60, max(2, 15.0 / max(time.perf_counter() - p0, 1e-3))))
+        o = orc.MMWOracle(nit=iters, eta=args.eta)
         c0 = time.perf_counter()
         o.run(Z, state, lambda i, K_, D_: orc.sketch_rows(rng.randn(K_, D_)), factor=False, pattern=pat)
         c1 = time.perf_counter()
