@@ -115,6 +115,13 @@ int mmw_bench_spmm(mmw_solver* s, int blocked, int reps, double* avg_us);
 int mmw_reset(mmw_solver* s, int32_t nit);
 
 /*
+ * mmw_set_slots: rebind the handle to another slot count Z on the SAME state (the binary search probes
+ * several Z per state, binary_search_relaxation.py:46-50): norm_H and the D = Z*rank_radio wide blocks are
+ * rebuilt, the pattern, its locality blocking and the device copies of the state are reused; then mmw_reset(nit).
+ */
+int mmw_set_slots(mmw_solver* s, int32_t Z, int32_t nit);
+
+/*
  * mmw_iterate: `n` passes of the loop body mmw.py:75-200 (averaging, DUAL, LOSS, EXPM), device resident.
  * randv: NULL -> the sketch of every iteration is generated on the device (Philox4x32-10 normals,
  * counter = (seed, iteration, row, column), rows normalised); otherwise n*K*D float64, iteration-major,

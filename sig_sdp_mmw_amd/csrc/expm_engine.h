@@ -108,6 +108,10 @@ template <typename T> struct ExpmEngine {
         indptr = ip;
         col = ci;
         val = v;
+        return resize(D);
+    }
+    // (re)allocate every width-dependent buffer for a block of D columns
+    int resize(int D) {
         std::string err;
         if (make_layout(D, V16<T>::N, lay, err) != MMW_OK) return fail(MMW_ERR_ARG, err);
         bs = (size_t)K * lay.Dpad;
@@ -123,7 +127,8 @@ template <typename T> struct ExpmEngine {
         MMW_TRY(plan_d.alloc(1));
         MMW_TRY(viol_d.alloc(1));
         MMW_HIP(hipMemsetAsync(viol_d.p, 0, sizeof(int), st));
-        MMW_HIP(hipHostMalloc((void**)&plan_h, sizeof(ExpmPlan)));
+        if (!plan_h) MMW_HIP(hipHostMalloc((void**)&plan_h, sizeof(ExpmPlan)));
+        if (use_blk) MMW_TRY(enable_blocking(blk, val_blk));
         MMW_HIP(hipMemsetAsync(U.p, 0, bs * (size_t)(MAX_ORDER + 1) * sizeof(T), st));
         return MMW_OK;
     }

@@ -71,9 +71,10 @@ inline double tridiag_min_eig(const std::vector<double>& a, const std::vector<do
 
 template <typename T> struct DenseWork {
     hipStream_t st = nullptr;
-    DevBuf<double> G, Q, Q2, Gpart, cs, diag, dscale, off, scale;
-    DevBuf<int> perm;
+    DevBuf<double> G, Q, Q2, G2, Q3, Gpart, cs, diag, dscale, off, scale;
+    DevBuf<int> perm, flag;
     int bcap = 0;
+    int sweeps_total = 0, calls_total = 0;
     int ensure(int b, int nslice) {
         if (b <= bcap && Gpart.n >= (size_t)nslice * b * b) return MMW_OK;
         bcap = std::max(b, bcap);
@@ -100,28 +101,49 @@ template <typename T> struct DenseWork {
         MMW_HIP(hipGetLastError());
         return MMW_OK;
     }
-    // in-place Jacobi of G (b x b) -> eigenvalues on the diagonal (copied to diag), eigenvectors in Q
+    // Jacobi of G (b x b) -> eigenvalues in `diag`, eigenvectors in Q (one launch per round, ping-pong buffers)
     int jacobi(int b, double rel_tol, int max_sweeps, int* sweeps_done = nullptr) {
         const int n = (b % 2 == 0) ? b : b + 1;
+        if (G2.n < (size_t)b * b) { MMW_TRY(G2.alloc((size_t)bcap * bcap)); MMW_TRY(Q3.alloc((size_t)bcap * bcap)); }
         hipLaunchKernelGGL(k_set_eye, dim3(grid_elems((size_t)b * b)), dim3(BLOCK), 0, st, b, Q.p);
         const int half = n / 2;
-        const int gp = (half + 63) / 64;
         const int ga = grid_elems((size_t)std::max(half * half, b * half));
         double h_off[2] = {0, 0};
+        double* Hc = G.p;
+        double* Hn = G2.p;
+        double* Qc = Q.p;
+        double* Qn = Q3.p;
         int sw = 0;
         for (; sw < max_sweeps; ++sw) {
-            hipLaunchKernelGGL(k_offdiag, dim3(1), dim3(BLOCK), 0, st, b, G.p, off.p);
+            hipLaunchKernelGGL(k_offdiag, dim3(1), dim3(BLOCK), 0, st, b, Hc, off.p);
             MMW_HIP(hipMemcpyAsync(h_off, off.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
             MMW_HIP(hipStreamSynchronize(st));
             if (!(std::sqrt(h_off[0]) > rel_tol * h_off[1] * std::sqrt((double)b)) || b < 2) break;
             for (int r = 0; r < n - 1; ++r) {
-                hipLaunchKernelGGL(k_jacobi_params, dim3(gp), dim3(64), 0, st, b, n, r, G.p, cs.p, 0.0);
-                hipLaunchKernelGGL(k_jacobi_apply, dim3(ga), dim3(BLOCK), 0, st, b, n, r, G.p, Q.p, cs.p);
+                hipLaunchKernelGGL(k_jacobi_round, dim3(ga), dim3(BLOCK), 0, st, b, n, r, Hc, Hn, Qc, Qn);
+                std::swap(Hc, Hn);
+                std::swap(Qc, Qn);
             }
             MMW_HIP(hipGetLastError());
         }
         if (sweeps_done) *sweeps_done = sw;
-        hipLaunchKernelGGL(k_get_diag, dim3(grid_elems(b)), dim3(BLOCK), 0, st, b, G.p, diag.p);
+        sweeps_total += sw;
+        calls_total += 1;
+        hipLaunchKernelGGL(k_get_diag, dim3(grid_elems(b)), dim3(BLOCK), 0, st, b, Hc, diag.p);
+        if (Qc != Q.p) MMW_HIP(hipMemcpyAsync(Q.p, Qc, (size_t)b * b * sizeof(double), hipMemcpyDeviceToDevice, st));
+        MMW_HIP(hipGetLastError());
+        return MMW_OK;
+    }
+    // Cholesky of the unit-diagonal Gram matrix D G D in place (G <- L); *ok = false when it is not numerically SPD
+    int chol_factor(int b, bool* ok) {
+        if (flag.n < 1) MMW_TRY(flag.alloc(1));
+        hipLaunchKernelGGL(k_scale_sym, dim3(grid_elems(b)), dim3(BLOCK), 0, st, b, G.p, dscale.p);
+        hipLaunchKernelGGL(k_apply_scale_sym, dim3(grid_elems((size_t)b * b)), dim3(BLOCK), 0, st, b, G.p, dscale.p);
+        hipLaunchKernelGGL(k_cholesky, dim3(1), dim3(1024), 0, st, b, G.p, flag.p);
+        int bad = 0;
+        MMW_HIP(hipMemcpyAsync(&bad, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        MMW_HIP(hipStreamSynchronize(st));
+        *ok = bad == 0;
         MMW_HIP(hipGetLastError());
         return MMW_OK;
     }
@@ -150,17 +172,27 @@ template <typename T> struct Factorizer {
         return MMW_OK;
     }
 
-    // V <- V * (D Q Lambda^{-1/2}) twice: columns orthonormal to rounding
+    // V <- V * F twice with F from the Gram matrix: Cholesky-QR (cheap) and, when the block is too
+    // ill-conditioned for it, the eigen-based factor D Q Lambda^{-1/2}; columns orthonormal to rounding
     int orthonormalise(int b, int ld, DevBuf<T>& A, DevBuf<T>& B, double eps) {
         for (int pass = 0; pass < 2; ++pass) {
             MMW_TRY(dw.gram(K, b, ld, A.p, A.p, true));
-            hipLaunchKernelGGL(k_scale_sym, dim3(grid_elems(b)), dim3(BLOCK), 0, st, b, dw.G.p, dw.dscale.p);
-            hipLaunchKernelGGL(k_apply_scale_sym, dim3(grid_elems((size_t)b * b)), dim3(BLOCK), 0, st, b, dw.G.p, dw.dscale.p);
-            MMW_TRY(dw.jacobi(b, 1e-15, 30));
-            hipLaunchKernelGGL(k_orth_factor, dim3(grid_elems((size_t)b * b)), dim3(BLOCK), 0, st, b, dw.Q.p, dw.dscale.p, dw.diag.p, eps,
-                               (double)b, dw.Q2.p);
-            MMW_HIP(hipMemsetAsync(B.p, 0, (size_t)K * ld * sizeof(T), st));
-            MMW_TRY(dw.gemm(K, b, b, ld, A.p, dw.Q2.p, b, B.p));
+            bool ok = false;
+            MMW_TRY(dw.chol_factor(b, &ok));
+            if (!ok) {
+                MMW_TRY(dw.gram(K, b, ld, A.p, A.p, true));  // the failed factorisation overwrote G
+                hipLaunchKernelGGL(k_scale_sym, dim3(grid_elems(b)), dim3(BLOCK), 0, st, b, dw.G.p, dw.dscale.p);
+                hipLaunchKernelGGL(k_apply_scale_sym, dim3(grid_elems((size_t)b * b)), dim3(BLOCK), 0, st, b, dw.G.p, dw.dscale.p);
+                MMW_TRY(dw.jacobi(b, 1e-14, 30));
+                hipLaunchKernelGGL(k_orth_factor, dim3(grid_elems((size_t)b * b)), dim3(BLOCK), 0, st, b, dw.Q.p, dw.dscale.p, dw.diag.p, eps,
+                                   (double)b, dw.Q2.p);
+                MMW_HIP(hipMemsetAsync(B.p, 0, (size_t)K * ld * sizeof(T), st));
+                MMW_TRY(dw.gemm(K, b, b, ld, A.p, dw.Q2.p, b, B.p));
+            } else {  // V <- (V D) L^{-T} by forward substitution on the rows
+                hipLaunchKernelGGL((k_trsm_rows<T>), dim3(grid_rows(K)), dim3(BLOCK), (size_t)WAVES_PER_BLOCK * b * sizeof(double), st, K, b, ld,
+                                   A.p, dw.G.p, dw.dscale.p, B.p);
+                MMW_HIP(hipGetLastError());
+            }
             std::swap(A.p, B.p);
         }
         return MMW_OK;
@@ -172,6 +204,7 @@ template <typename T> struct Factorizer {
         const bool f32 = sizeof(T) == 4;
         const double tol = f32 ? 2e-5 : 1e-9;
         int b = std::min(K, rank + std::max(16, rank / 4));
+        if (K <= 384 || 4 * b >= 3 * K) b = K;  // small or nearly full: one exact Rayleigh-Ritz on the whole space
         BlockLayout lay;
         std::string err;
         if (make_layout(b, V16<T>::N, lay, err) != MMW_OK) return fail(MMW_ERR_ARG, "mmw_factor: " + err);
@@ -200,12 +233,13 @@ template <typename T> struct Factorizer {
         const int max_outer = 40;
         int outer = 0;
         bool done = false;
-        int degree = 8;
+        double prev_resid = -1.0;
+        int degree = 12;  // filter degree schedule 12, 30, 40, 40, ...: few Rayleigh-Ritz / orthonormalisation rounds
         for (; outer < max_outer && !done; ++outer) {
             // ---- Rayleigh-Ritz on span(V)
             MMW_TRY((spmm_launch<T, SPMM_PLAIN>(st, K, lay, nblk, indptr, col, val, V.p, W.p, nullptr, nullptr, ascale, 0.0, 0.0, nullptr)));
             MMW_TRY(dw.gram(K, b, ld, V.p, W.p, true));
-            MMW_TRY(dw.jacobi(b, 1e-15, 30));
+            MMW_TRY(dw.jacobi(b, f32 ? 1e-8 : 1e-13, 30));
             MMW_HIP(hipMemcpyAsync(theta.data(), dw.diag.p, b * sizeof(double), hipMemcpyDeviceToHost, st));
             MMW_HIP(hipStreamSynchronize(st));
             std::iota(perm.begin(), perm.end(), 0);
@@ -235,6 +269,7 @@ template <typename T> struct Factorizer {
             }
             const double scale_top = std::max(std::fabs(theta[0]), 1e-300);
             last_resid = worst / scale_top;
+            if (getenv("MMW_FACTOR_VERBOSE")) fprintf(stderr, "[factor]   outer %d degree %d resid %.2e\n", outer, degree, last_resid);
             if (b >= K || last_resid <= tol) {
                 done = true;
                 break;
@@ -272,10 +307,16 @@ template <typename T> struct Factorizer {
                 if (cur == Y1.p) Y1.p = oldV; else Y2.p = oldV;
             }
             MMW_TRY(orthonormalise(b, ld, V, W, 1e-14));
-            degree = std::min(40, degree + 4);
+            // adaptive degree: grow while the residual keeps falling, back off when rounding stalls the filter
+            if (prev_resid > 0.0 && last_resid > 0.5 * prev_resid) degree = std::max(4, degree / 2);
+            else degree = degree < 30 ? 30 : 40;
+            prev_resid = last_resid;
         }
         outer_done = outer;
         if (kt) MMW_TRY(kt->end());
+        if (getenv("MMW_FACTOR_VERBOSE"))
+            fprintf(stderr, "[factor] K=%d rank=%d b=%d outer=%d degree_last=%d resid=%.2e jacobi_sweeps=%d jacobi_calls=%d\n", K, rank, b, outer, degree,
+                    last_resid, dw.sweeps_total, dw.calls_total);
         if (!done && last_resid > 100 * tol)
             return fail(MMW_ERR_STATE, "mmw_factor: subspace iteration did not converge (relative residual " + std::to_string(last_resid) + ")");
         // ---- X_half = V[:, top rank] sqrt|theta|, columns in ascending |theta| (svds order, mmw.py:215-216)

@@ -126,16 +126,13 @@ __device__ __forceinline__ void jacobi_pair(int n, int r, int i, int& p, int& q)
         q = t;
     }
 }
-// rotation parameters for every pair of round r
-__global__ void k_jacobi_params(int b, int n, int r, const double* __restrict__ H, double* __restrict__ cs, double thresh) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n / 2) return;
-    int p, q;
-    jacobi_pair(n, r, i, p, q);
-    double c = 1.0, s = 0.0;
+// rotation (c, s) that annihilates H[p][q]
+__device__ __forceinline__ void jacobi_cs(const double* __restrict__ H, int b, int p, int q, double& c, double& s) {
+    c = 1.0;
+    s = 0.0;
     if (q < b) {
         const double apq = H[(size_t)p * b + q];
-        if (fabs(apq) > thresh) {
+        if (apq != 0.0) {
             const double app = H[(size_t)p * b + p], aqq = H[(size_t)q * b + q];
             const double tau = (aqq - app) / (2.0 * apq);
             const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
@@ -143,12 +140,12 @@ __global__ void k_jacobi_params(int b, int n, int r, const double* __restrict__ 
             s = t * c;
         }
     }
-    cs[2 * i] = c;
-    cs[2 * i + 1] = s;
 }
-// H <- J^T H J on 2x2 blocks (pair i, pair j);  Q <- Q J on (row x, pair j)
-__global__ __launch_bounds__(BLOCK) void k_jacobi_apply(int b, int n, int r, double* __restrict__ H, double* __restrict__ Q,
-                                                        const double* __restrict__ cs) {
+// one Jacobi round in ONE launch, ping-pong buffers: Hout = J^T Hin J on 2x2 blocks (pair i, pair j), Qout = Qin J.
+// Every thread rebuilds the two rotations it needs from the untouched input matrix, so there is no
+// separate parameter pass and no race.
+__global__ __launch_bounds__(BLOCK) void k_jacobi_round(int b, int n, int r, const double* __restrict__ Hin, double* __restrict__ Hout,
+                                                        const double* __restrict__ Qin, double* __restrict__ Qout) {
     const int half = n / 2;
     const int total = half * half;
     for (int o = blockIdx.x * BLOCK + threadIdx.x; o < total; o += gridDim.x * BLOCK) {
@@ -156,36 +153,92 @@ __global__ __launch_bounds__(BLOCK) void k_jacobi_apply(int b, int n, int r, dou
         int pi, qi, pj, qj;
         jacobi_pair(n, r, i, pi, qi);
         jacobi_pair(n, r, j, pj, qj);
-        const double ci = cs[2 * i], si = cs[2 * i + 1], cj = cs[2 * j], sj = cs[2 * j + 1];
+        double ci, si, cj, sj;
+        jacobi_cs(Hin, b, pi, qi, ci, si);
+        jacobi_cs(Hin, b, pj, qj, cj, sj);
         const bool qi_ok = qi < b, qj_ok = qj < b;
-        // block [[h_pp, h_pq],[h_qp, h_qq]] with rows (pi, qi) and columns (pj, qj)
-        double h00 = H[(size_t)pi * b + pj];
-        double h01 = qj_ok ? H[(size_t)pi * b + qj] : 0.0;
-        double h10 = qi_ok ? H[(size_t)qi * b + pj] : 0.0;
-        double h11 = (qi_ok && qj_ok) ? H[(size_t)qi * b + qj] : 0.0;
-        // rows: J_i^T with J = [[c, s],[-s, c]]
+        double h00 = Hin[(size_t)pi * b + pj];
+        double h01 = qj_ok ? Hin[(size_t)pi * b + qj] : 0.0;
+        double h10 = qi_ok ? Hin[(size_t)qi * b + pj] : 0.0;
+        double h11 = (qi_ok && qj_ok) ? Hin[(size_t)qi * b + qj] : 0.0;
         const double t00 = ci * h00 - si * h10, t01 = ci * h01 - si * h11;
         const double t10 = si * h00 + ci * h10, t11 = si * h01 + ci * h11;
-        // columns: * J_j
         h00 = t00 * cj - t01 * sj;
         h01 = t00 * sj + t01 * cj;
         h10 = t10 * cj - t11 * sj;
         h11 = t10 * sj + t11 * cj;
-        H[(size_t)pi * b + pj] = h00;
-        if (qj_ok) H[(size_t)pi * b + qj] = h01;
-        if (qi_ok) H[(size_t)qi * b + pj] = h10;
-        if (qi_ok && qj_ok) H[(size_t)qi * b + qj] = h11;
+        Hout[(size_t)pi * b + pj] = h00;
+        if (qj_ok) Hout[(size_t)pi * b + qj] = h01;
+        if (qi_ok) Hout[(size_t)qi * b + pj] = h10;
+        if (qi_ok && qj_ok) Hout[(size_t)qi * b + qj] = h11;
     }
     const int totq = b * half;
     for (int o = blockIdx.x * BLOCK + threadIdx.x; o < totq; o += gridDim.x * BLOCK) {
         const int x = o / half, j = o % half;
         int pj, qj;
         jacobi_pair(n, r, j, pj, qj);
-        if (qj >= b) continue;
-        const double cj = cs[2 * j], sj = cs[2 * j + 1];
-        const double a = Q[(size_t)x * b + pj], d = Q[(size_t)x * b + qj];
-        Q[(size_t)x * b + pj] = a * cj - d * sj;
-        Q[(size_t)x * b + qj] = a * sj + d * cj;
+        const double a = Qin[(size_t)x * b + pj];
+        if (qj >= b) {
+            Qout[(size_t)x * b + pj] = a;
+            continue;
+        }
+        double cj, sj;
+        jacobi_cs(Hin, b, pj, qj, cj, sj);
+        const double d = Qin[(size_t)x * b + qj];
+        Qout[(size_t)x * b + pj] = a * cj - d * sj;
+        Qout[(size_t)x * b + qj] = a * sj + d * cj;
+    }
+}
+// ---- Cholesky G = L L^T in place (lower triangle), one workgroup; *flag = 1 when a pivot is not positive
+__global__ __launch_bounds__(1024) void k_cholesky(int b, double* __restrict__ G, int* __restrict__ flag) {
+    __shared__ double dj;
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    for (int j = 0; j < b; ++j) {
+        if (threadIdx.x == 0) {
+            const double g = G[(size_t)j * b + j];
+            if (!(g > 0.0)) bad = 1;
+            dj = g > 0.0 ? sqrt(g) : 1.0;
+            G[(size_t)j * b + j] = dj;
+        }
+        __syncthreads();
+        if (bad) break;
+        const double inv = 1.0 / dj;
+        for (int i = j + 1 + threadIdx.x; i < b; i += blockDim.x) G[(size_t)i * b + j] *= inv;
+        __syncthreads();
+        // trailing update of the lower triangle: (i, k) with j < k <= i < b
+        const int m = b - j - 1;
+        for (int o = threadIdx.x; o < m * m; o += blockDim.x) {
+            const int i = j + 1 + o / m, k = j + 1 + o % m;
+            if (k <= i) G[(size_t)i * b + k] -= G[(size_t)i * b + j] * G[(size_t)k * b + j];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *flag = bad;
+}
+// ---- Vout[r,:] = (V[r,:] * dscale) L^{-T}: forward substitution per block row, one wavefront per row.
+// x_j = (v_j d_j - sum_{i<j} x_i L[j][i]) / L[j][j]; the running x lives in LDS, row j of L is read coalesced.
+// This is the orthonormalising right factor of Cholesky-QR applied without ever forming an inverse.
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_trsm_rows(int K, int b, int ld, const T* __restrict__ V, const double* __restrict__ L,
+                                                     const double* __restrict__ dscale, T* __restrict__ Vout) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* xs = reinterpret_cast<double*>(smem_raw);  // [WAVES_PER_BLOCK][b]
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    double* x = xs + (size_t)wib * b;
+    for (int row = blockIdx.x * WAVES_PER_BLOCK + wib; row < K; row += gridDim.x * WAVES_PER_BLOCK) {
+        for (int j = 0; j < b; ++j) {
+            double s = 0.0;
+            const double* Lj = L + (size_t)j * b;
+            for (int i = lane; i < j; i += WAVE) s += x[i] * Lj[i];
+            s = wave_sum(s);
+            if (lane == 0) x[j] = ((double)V[(size_t)row * ld + j] * dscale[j] - s) / Lj[j];
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): x[j] is in LDS before the next step reads it
+        }
+        for (int j = lane; j < b; j += WAVE) Vout[(size_t)row * ld + j] = (T)x[j];
+        for (int j = b + lane; j < ld; j += WAVE) Vout[(size_t)row * ld + j] = T(0);
     }
 }
 // off-diagonal Frobenius norm^2 and diagonal scale: out[0] = sum_{i != j} H_ij^2, out[1] = max |H_ii|

@@ -20,6 +20,7 @@ struct mmw_solver {
     virtual int set_profile(int enabled) = 0;
     virtual int bench_spmm(int blocked, int reps, double* avg_us) = 0;
     virtual int reset(int32_t nit) = 0;
+    virtual int set_slots(int32_t Z, int32_t nit) = 0;
     virtual int iterate(int32_t n, const double* randv, uint64_t seed) = 0;
     virtual int sync() = 0;
     virtual int read_f64(int which, double* out, int64_t n) = 0;
@@ -237,6 +238,27 @@ template <typename T> struct Solver final : mmw_solver {
         return MMW_OK;
     }
 
+    // same state, new slot count: only the Z-dependent scalars and the D-wide blocks change
+    int set_slots(int32_t Z_, int32_t nit_) override {
+        if (host_only) return fail(MMW_ERR_STATE, "this handle was created with device -1 (host pattern only)");
+        MMW_HIP(hipSetDevice(device));
+        MMW_TRY(settle());
+        MMW_HIP(hipStreamSynchronize(st));
+        std::string err = update_slots(H, Z_);
+        if (!err.empty()) return fail(MMW_ERR_ARG, "mmw_set_slots: " + err);
+        Z = Z_;
+        D = Z * rank_radio;
+        std::vector<double> invn(K);
+        for (int k = 0; k < K; ++k) invn[k] = 1.0 / H.norm_H[k];
+        MMW_TRY(d_invn.upload_cast(invn, st));
+        MMW_TRY(d_cH.upload_cast(H.cH, st));
+        MMW_TRY(eng.resize(D));
+        MMW_TRY(Xh.alloc(eng.bs));
+        const size_t nnz = (size_t)H.nnzL(), C = (size_t)H.C();
+        MMW_TRY(out64.alloc(std::max(std::max(nnz, C), eng.bs)));
+        MMW_TRY(stage64.alloc((size_t)K * D));
+        return reset(nit_);
+    }
     int reset(int32_t nit_) override {
         if (host_only) return fail(MMW_ERR_STATE, "this handle was created with device -1 (host pattern only)");
         MMW_HIP(hipSetDevice(device));
@@ -646,6 +668,7 @@ int mmw_set_timing(mmw_solver* s, int enabled) { MMW_NEED(s); return s->set_timi
 int mmw_set_profile(mmw_solver* s, int enabled) { MMW_NEED(s); return s->set_profile(enabled); }
 int mmw_bench_spmm(mmw_solver* s, int blocked, int reps, double* avg_us) { MMW_NEED(s); return s->bench_spmm(blocked, reps, avg_us); }
 int mmw_reset(mmw_solver* s, int32_t nit) { MMW_NEED(s); return s->reset(nit); }
+int mmw_set_slots(mmw_solver* s, int32_t Z, int32_t nit) { MMW_NEED(s); return s->set_slots(Z, nit); }
 int mmw_iterate(mmw_solver* s, int32_t n, const double* randv, uint64_t seed) { MMW_NEED(s); return s->iterate(n, randv, seed); }
 int mmw_sync(mmw_solver* s) { MMW_NEED(s); return s->sync(); }
 int mmw_read_f64(mmw_solver* s, int which, double* out, int64_t n) { MMW_NEED(s); if (!out && n) return fail(MMW_ERR_ARG, "null output"); return s->read_f64(which, out, n); }

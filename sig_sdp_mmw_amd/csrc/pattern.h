@@ -48,6 +48,24 @@ static inline bool row_has(const int32_t* idx, int32_t lo, int32_t hi, int32_t c
     return false;
 }
 
+// the Z-dependent scalars (mmw.py:39,167): everything else in HostPattern is independent of the slot count
+static inline std::string update_slots(HostPattern& P, int32_t Z) {
+    if (Z < 2) return "Z must be >= 2 (the constraints divide by Z-1)";
+    const int32_t K = P.K;
+    P.Z = Z;
+    for (int32_t k = 0; k < K; ++k) {
+        double q = 0.0;
+        for (int32_t i = P.st_indptr[k]; i < P.st_indptr[k + 1]; ++i) q += P.st_data[i] * P.st_data[i];
+        const double s = P.S_sum[k];
+        const double invK = 1.0 / (double)K;
+        const double c = invK * P.h_max[k] - invK / (double)Z * s;
+        P.norm_H[k] = std::sqrt(q) * (double)(Z - 1) / (double)(2 * Z) + std::fabs(c);
+        P.cH[k] = 1.0 / (double)K * P.h_max[k] - 1.0 / ((double)K * (double)Z) * s;
+        if (!(P.norm_H[k] > 0.0)) return "norm_H has a zero entry (user with no interferers and h_max == 0)";
+    }
+    return "";
+}
+
 // returns "" on success, else an error message
 static inline std::string build_pattern(HostPattern& P, int32_t K, int32_t Z, const int32_t* Sp, const int32_t* Si,
                                         const double* Sx, const int32_t* Qp, const int32_t* Qi, const double* Qx,

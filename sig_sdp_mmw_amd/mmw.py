@@ -48,6 +48,7 @@ class mmw(STATS_OBJECT, sdp_solver):
         self.seed = int(seed)
         self._runs = 0
         self.last_expm_info = None
+        self.round_batch = rng == "device"  # the fast path batches the rounding attempts too
 
     def run_with_state(self, bs_iteration, Z, state):
         tic = self._get_tic()

@@ -44,8 +44,11 @@ class sdp_solver:
 
     def _device_solver(self, Z, state, nit=1, eta=0.1, need_loop=False):
         """A device handle holding `state` (reused across the binary search's solve/rounding pairs)."""
-        if not need_loop and self._same_state(state):
-            return self._dev[2]
+        if self._same_state(state):
+            s = self._dev[2]
+            if need_loop:  # same state, another slot count: keep pattern, blocking and device copies
+                s.set_slots(max(int(Z), 2), max(int(nit), 1))
+            return s
         if self._dev is not None:
             self._dev[2].close()
         s = _lib.Solver(max(int(Z), 2), state, max(int(nit), 1), eta, rank_radio=self.rank_radio, dtype=self._dtype_code,
@@ -56,7 +59,11 @@ class sdp_solver:
     def run_with_state(self, bs_iteration, Z, state):
         pass
 
+    round_batch = False  # True: all attempts of one rounding() call in a single device launch
+
     def rounding(self, Z, gX, state, nattempt=10):
+        if self.round_batch and nattempt > 1:
+            return self._rounding_batched(Z, gX, state, nattempt)
         z_vec = None
         remainder = None
         for n in range(nattempt):
@@ -64,6 +71,25 @@ class sdp_solver:
             if remainder == 0:
                 return z_vec, Z, remainder
         return z_vec, Z, remainder
+
+    def _rounding_batched(self, Z, gX, state, nattempt):
+        """The `nattempt` independent attempts of sdp_solver.py:18-25 as one batch (one workgroup each); the
+        first feasible one wins, like the sequential loop.  Draws all projection vectors up front, so the
+        global NumPy stream is consumed differently from the reference (use round_batch=False for parity)."""
+        gX = np.ascontiguousarray(gX, dtype=np.float64)
+        D = gX.shape[1]
+        randv = np.random.randn(nattempt, Z, D)
+        randv = randv / np.linalg.norm(randv, axis=2, keepdims=True)
+        solver = self._device_solver(Z, state)
+        z, rem = solver.round(int(Z), gX, randv)
+        ok = np.nonzero(rem == 0)[0]
+        pick = int(ok[0]) if ok.size else nattempt - 1
+        z = z[pick]
+        not_assigned = z < 0
+        z_vec = z.astype(np.float64)
+        if np.any(not_assigned):
+            z_vec[not_assigned] = np.random.randint(Z, size=int(not_assigned.sum()))
+        return z_vec, Z, np.sum(not_assigned)
 
     def rounding_one_attempt(self, Z, gX, state):
         gX = np.ascontiguousarray(gX, dtype=np.float64)

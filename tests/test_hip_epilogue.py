@@ -120,3 +120,29 @@ def test_class_device_rng_fp32_runs_and_is_feasible():
     out = mmw.expm_half_randsk(L, 6)
     assert out.shape == (K, 6)
     np.testing.assert_allclose(np.linalg.norm(out, axis=1), np.exp(0.01), rtol=1e-10)
+
+
+def test_binary_search_end_to_end_on_device():
+    """bs.run with the device solver: converges to a feasible colouring within the reference's bracket."""
+    from sig_sdp_mmw_amd.binary_search import binary_search_relaxation
+    g = load_golden("bs_run")
+    for name in ("env75", "env108"):
+        state = state_from(g, name + "_")
+        bs = binary_search_relaxation()
+        bs.verbose = False
+        alg = mmw(nit=30, eta=0.04)
+        bs.feasibility_check_alg = alg
+        np.random.seed(int(g[name + "_seed"]))
+        z_vec, Z, rem = bs.run(state)
+        lb, ub = (int(x) for x in g[name + "_bounds"][0])
+        assert rem == 0 and lb <= Z <= ub
+        assert abs(Z - int(g[name + "_Z"])) <= 2  # same problem, different factor rotation -> same slot count +-
+        # the colouring is feasible: per slot no shared AP and interference within h_max
+        S, Q, h = state
+        Sd = S.toarray()
+        np.fill_diagonal(Sd, 0)
+        for zz in range(Z):
+            mem = np.where(z_vec == zz)[0]
+            if mem.size:
+                assert np.all(Sd[np.ix_(mem, mem)].sum(axis=0) <= h[mem] + 1e-12)
+                assert Q[np.ix_(mem, mem)].nnz == 0
