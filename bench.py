@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--dtype", default=None, choices=["f32", "f64"])
     ap.add_argument("--eta", type=float, default=0.04)
     ap.add_argument("--cpu-iters", type=int, default=-1, help="oracle iterations for cpu_baseline (-1: auto, 0: skip)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --single-device rehearses N>1 on a 1-GPU box")
+    ap.add_argument("--single-device", action="store_true", help="every rank uses GPU 0 (rehearsal only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -82,13 +84,19 @@ def main():
 
     import torch
     dist = None
+    if args.single_device:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
     else:
         torch.cuda.set_device(local_rank)
+    coll_dev = "cuda" if args.backend == "nccl" else "cpu"
 
     from sig_sdp_mmw_amd import _lib
 
@@ -106,6 +114,7 @@ def main():
     seed = 1234 + rank
 
     def barrier():
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -117,16 +126,16 @@ def main():
     t0 = time.perf_counter()
     solver.iterate(args.steps, None, seed)
     solver.sync()
-    obj = np.array([rank, Z, float(np.max(solver.read(_lib.F_E_THIS))), args.steps, 0.0], dtype=np.float64)
-    if dist is not None:
-        mine = torch.tensor(obj, device="cuda")
-        allobj = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(allobj, mine)  # RCCL over xGMI: per-instance objectives, ~40 B per rank
+    from sig_sdp_mmw_amd import sharding
+    # per-instance objective record, gathered to every rank (RCCL all_gather over xGMI, 48 B per instance)
+    rec = [rank, Z, 0.0, float(np.max(solver.read(_lib.F_E_THIS))), args.steps, (time.perf_counter() - t0) * 1e6]
+    table = sharding.gather_records([rec], world, rank, world, dist=dist, device=coll_dev if dist is not None else None)
+    assert table.shape[0] == world
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     info = solver.read(_lib.F_EXPM_INFO)
@@ -168,6 +177,7 @@ def main():
                    "instances": world, "parallelism": "instance-sharded x%d" % world},
         "roofline": roofline,
         "device_us_per_step": phases,
+        "objectives": {"max_violation_per_instance": [round(float(x), 6) for x in table[:, 3]]},
     }
 
     # ---- CPU baseline: the oracle on this host, bounded sample of the same instance (rank 0, N = 1 only)
