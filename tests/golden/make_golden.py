@@ -218,7 +218,32 @@ def synthetic_state(K, p, seed):
     return er_contention_graph(K, p, seed)
 
 
+def record_eval():
+    """env.evaluate_sinr / evaluate_bler (sim_src/env/env.py:198-236) on the colourings of bs_run.npz."""
+    bs = np.load(os.path.join(HERE, "bs_run.npz"), allow_pickle=False)
+    out = {"meta": np.array(META)}
+    for name, cs, seed in (("env75", 5, 0), ("env108", 6, 2)):
+        e = env(cell_size=cs, sta_density_per_1m2=75e-4, seed=seed)
+        z_vec, Z = bs[name + "_z_vec"], int(bs[name + "_Z"])
+        out[name + "_cell_size"] = np.array(cs)
+        out[name + "_seed"] = np.array(seed)
+        out[name + "_z_vec"] = z_vec
+        out[name + "_Z"] = np.array(Z)
+        out[name + "_sinr"] = e.evaluate_sinr(z_vec, Z)
+        out[name + "_bler"] = e.evaluate_bler(z_vec, Z)
+        # a deliberately bad colouring: everybody in 3 slots -> collisions on shared APs, low SINR
+        zb = np.arange(z_vec.size) % 3
+        out[name + "_sinr_bad"] = e.evaluate_sinr(zb.astype(float), 3)
+        out[name + "_bler_bad"] = e.evaluate_bler(zb.astype(float), 3)
+    path = os.path.join(HERE, "eval.npz")
+    np.savez_compressed(path, **out)
+    print("eval %.0f KB" % (os.path.getsize(path) / 1024))
+
+
 def main():
+    if "--only-eval" in sys.argv:
+        record_eval()
+        return
     cases = [
         # name, state factory, Z, nit, eta, seed, log_gap, Z_round (slot count used for the tight rounding fixture)
         ("env75", lambda: env(cell_size=5, sta_density_per_1m2=75e-4, seed=0).generate_S_Q_hmax(), 27, 8, 0.04, 11, True),
@@ -298,6 +323,7 @@ def main():
     path = os.path.join(HERE, "bs_run.npz")
     np.savez_compressed(path, **bs_out)
     print("bs_run %.0f KB" % (os.path.getsize(path) / 1024))
+    record_eval()
 
 
 if __name__ == "__main__":
