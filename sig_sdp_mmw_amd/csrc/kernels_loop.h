@@ -144,12 +144,14 @@ __global__ __launch_bounds__(BLOCK) void k_softmax_b(int C, T* __restrict__ Y, T
 }
 
 // ---- LOSS: lval -= eta * (LD + LF + LH) on the pattern; per-block partial of the diagonal sum ------
+// One thread per stored entry (row ids from `lrow`): every array is read fully coalesced, the only gathers
+// are the two dual weights of a gain edge.
 template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_loss(PatternDev<T> P, const T* __restrict__ Y, const double* __restrict__ scal,
-                                                T* __restrict__ lval, double eta, double* __restrict__ trace_part,
-                                                const int* __restrict__ bpos, T* __restrict__ lval_blk) {
+__global__ __launch_bounds__(BLOCK) void k_loss(PatternDev<T> P, const int* __restrict__ lrow, const T* __restrict__ Y,
+                                                const double* __restrict__ scal, T* __restrict__ lval, double eta,
+                                                double* __restrict__ trace_part, const int* __restrict__ bpos,
+                                                T* __restrict__ lval_blk) {
     __shared__ double sh[WAVES_PER_BLOCK];
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int K = P.K, Z = P.Z, baseF = K, baseH = K + P.E_asso;
     const double invK = 1.0 / (double)K, Zm1 = (double)(Z - 1);
     const double cF = 0.5 + 1.0 / ((double)K * Zm1);
@@ -157,24 +159,22 @@ __global__ __launch_bounds__(BLOCK) void k_loss(PatternDev<T> P, const T* __rest
     const double dconst = -(sumYD * invK) / (1.0 - invK) + (sumYF / ((double)K * Zm1)) / cF - sumW;
     const double gscale = Zm1 / (double)(2 * Z);
     double tr = 0.0;
-    for (int row = blockIdx.x * WAVES_PER_BLOCK + wib; row < K; row += gridDim.x * WAVES_PER_BLOCK) {
-        const double w_row = (double)Y[baseH + row] * (double)P.inv_norm_H[row];
-        for (int e = P.indptr[row] + lane; e < P.indptr[row + 1]; e += WAVE) {
-            const int c = P.col[e];
-            double add;
-            if (c == row) {
-                add = (double)Y[row] / (1.0 - invK) + dconst;
-            } else if (P.pid[e] >= 0) {
-                add = ((double)Y[baseF + P.pid[e]] * 0.5) / cF;
-            } else {
-                const double w_col = (double)Y[baseH + c] * (double)P.inv_norm_H[c];
-                add = ((double)P.sab[e] * w_col + (double)P.sba[e] * w_row) * gscale;  // column-scaled S_T' symmetrised
-            }
-            const T nv = (T)((double)lval[e] - eta * add);
-            lval[e] = nv;
-            if (bpos) lval_blk[bpos[e]] = nv;  // the same value in the LDS-staged kernel's traversal order
-            if (c == row) tr += (double)nv;
+    for (int e = blockIdx.x * BLOCK + threadIdx.x; e < P.nnzL; e += gridDim.x * BLOCK) {
+        const int row = lrow[e], c = P.col[e];
+        double add;
+        if (c == row) {
+            add = (double)Y[row] / (1.0 - invK) + dconst;
+        } else if (P.pid[e] >= 0) {
+            add = ((double)Y[baseF + P.pid[e]] * 0.5) / cF;
+        } else {
+            const double w_row = (double)Y[baseH + row] * (double)P.inv_norm_H[row];
+            const double w_col = (double)Y[baseH + c] * (double)P.inv_norm_H[c];
+            add = ((double)P.sab[e] * w_col + (double)P.sba[e] * w_row) * gscale;  // column-scaled S_T' symmetrised
         }
+        const T nv = (T)((double)lval[e] - eta * add);
+        lval[e] = nv;
+        if (bpos) lval_blk[bpos[e]] = nv;  // the same value in the LDS-staged kernel's traversal order
+        if (c == row) tr += (double)nv;
     }
     tr = block_sum(tr, sh);
     if (threadIdx.x == 0) trace_part[blockIdx.x] = tr;

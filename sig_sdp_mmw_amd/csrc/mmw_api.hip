@@ -42,7 +42,7 @@ template <typename T> struct Solver final : mmw_solver {
     double eta = 0.1;
     bool timing = false;
     // pattern on the device
-    DevBuf<int> d_indptr, d_col, d_pid, d_mirror, d_diag, d_apos;
+    DevBuf<int> d_indptr, d_col, d_pid, d_mirror, d_diag, d_apos, d_lrow;
     DevBuf<T> d_sab, d_sba, d_h, d_ssum, d_invn, d_cH;
     // iterate state
     DevBuf<T> lval, xval, xavg, Y, yavg, e_accu, e_this, rsum, Xh, drow;
@@ -105,6 +105,12 @@ template <typename T> struct Solver final : mmw_solver {
         MMW_TRY(d_mirror.upload(H.mirror, st));
         MMW_TRY(d_diag.upload(H.diag_pos, st));
         MMW_TRY(d_apos.upload(H.asso_pos, st));
+        {
+            std::vector<int32_t> lrow((size_t)H.nnzL());
+            for (int k = 0; k < K; ++k)
+                for (int e = H.l_indptr[k]; e < H.l_indptr[k + 1]; ++e) lrow[e] = k;
+            MMW_TRY(d_lrow.upload(lrow, st));
+        }
         MMW_TRY(d_sab.upload_cast(H.sab, st));
         MMW_TRY(d_sba.upload_cast(H.sba, st));
         MMW_TRY(d_h.upload_cast(H.h_max, st));
@@ -362,6 +368,7 @@ template <typename T> struct Solver final : mmw_solver {
         const int gr = grid_rows(K);
         const int C = (int)H.C();
         const int gc = grid_elems((size_t)C);
+        const int gl = std::min(grid_elems((size_t)H.nnzL()), MAX_PART);  // LOSS: one thread per stored entry
         const int Dpad = eng.lay.Dpad;
         int m_launch = optimistic ? m_guess : 0;
         for (int it = 0; it < n; ++it) {
@@ -382,7 +389,7 @@ template <typename T> struct Solver final : mmw_solver {
             MMW_TRY(record(1));
             // ---- LOSS
             MMW_TRY(kt.begin(KT_LOSS));
-            hipLaunchKernelGGL((k_loss<T>), dim3(gr), dim3(BLOCK), 0, st, P, Y.p, scal.p, lval.p, eta, trace_part.p,
+            hipLaunchKernelGGL((k_loss<T>), dim3(gl), dim3(BLOCK), 0, st, P, d_lrow.p, Y.p, scal.p, lval.p, eta, trace_part.p,
                                (const int*)(eng.use_blk ? b_bpos.p : nullptr), lval_blk.p);
             MMW_TRY(kt.end());
             MMW_TRY(record(2));
@@ -406,7 +413,7 @@ template <typename T> struct Solver final : mmw_solver {
             MMW_HIP(hipGetLastError());
             eng.rownorm_d = drow.p;  // the Lanczos combination also emits the row norms and the trace slabs
             eng.rownorm_part = tr_part.p;
-            MMW_TRY(eng.apply(Xh.p, 0.5, trace_part.p, gr, m_launch));
+            MMW_TRY(eng.apply(Xh.p, 0.5, trace_part.p, gl, m_launch));
             MMW_TRY(kt.begin(KT_SDDMM));
             if (eng.method != MMW_EXPM_LANCZOS)
                 hipLaunchKernelGGL((k_rownorm2<T>), dim3(gr), dim3(BLOCK), 0, st, K, Dpad, Xh.p, drow.p, tr_part.p);
@@ -537,7 +544,7 @@ template <typename T> struct Solver final : mmw_solver {
         MMW_HIP(hipSetDevice(device));
         MMW_TRY(settle());
         if (iter >= nit) return fail(MMW_ERR_STATE, "mmw_gap: call it before an iteration (the running sums then hold iter+1 terms)");
-        return extras.gap(pat(), xavg.p, yavg.p, iter + 1, out);
+        return extras.gap(pat(), d_lrow.p, xavg.p, yavg.p, iter + 1, out);
     }
     int factor(int32_t rank, double* out, uint64_t seed) override {
         if (host_only) return fail(MMW_ERR_STATE, "host-only handle");

@@ -39,7 +39,7 @@ template <typename T> struct Extras {
     }
 
     // ---- LOG_GAP (mmw.py:79-117): nterms = number of X / Y terms in the running sums
-    int gap(const PatternDev<T>& P, const T* xavg, const T* yavg, int nterms, double out[3]) {
+    int gap(const PatternDev<T>& P, const int* lrow, const T* xavg, const T* yavg, int nterms, double out[3]) {
         const size_t nnz = (size_t)P.nnzL, C = (size_t)P.C;
         const int gr = grid_rows(K);
         MMW_TRY(ensure(g_x, nnz)); MMW_TRY(ensure(g_l, nnz)); MMW_TRY(ensure(g_y, C)); MMW_TRY(ensure(g_e1, C)); MMW_TRY(ensure(g_e2, C));
@@ -55,7 +55,7 @@ template <typename T> struct Extras {
         // L(Ybar) on the pattern
         hipLaunchKernelGGL((k_ysums<T>), dim3(1), dim3(BLOCK), 0, st, K, P.E_asso, g_y.p, P.cH, P.inv_norm_H, g_scal.p);
         MMW_HIP(hipMemsetAsync(g_l.p, 0, nnz * sizeof(T), st));
-        hipLaunchKernelGGL((k_loss<T>), dim3(gr), dim3(BLOCK), 0, st, P, g_y.p, g_scal.p, g_l.p, -1.0, g_trace.p, (const int*)nullptr, (T*)nullptr);
+        hipLaunchKernelGGL((k_loss<T>), dim3(gr), dim3(BLOCK), 0, st, P, lrow, g_y.p, g_scal.p, g_l.p, -1.0, g_trace.p, (const int*)nullptr, (T*)nullptr);
         MMW_HIP(hipGetLastError());
         double emax = 0.0;
         MMW_HIP(hipMemcpyAsync(&emax, g_scal.p + 4, sizeof(double), hipMemcpyDeviceToHost, st));
