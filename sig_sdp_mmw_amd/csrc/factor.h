@@ -171,6 +171,22 @@ template <typename T> struct Factorizer {
         st = s; K = K_; kt = k; dw.st = s;
         return MMW_OK;
     }
+    // optional locality blocking of the pattern (same structure the MMW loop uses): the factor's SpMMs then run on
+    // the LDS-staged kernel with the matrix values gathered once into the blocked traversal order
+    bool have_blk = false;
+    BlkDev blk{};
+    const int* bepos = nullptr;
+    int64_t nent = 0;
+    DevBuf<T> val_blk;
+    void set_blocking(const BlkDev& b, const int* blocked_to_csr, int64_t entries) {
+        blk = b; bepos = blocked_to_csr; nent = entries; have_blk = true;
+    }
+    template <int MODE>
+    int spmm(const BlockLayout& lay, int nblk, const int* indptr, const int* col, const T* val, const T* in, T* outp, T* Fp, const T* X2p,
+             double c1, double c2, double c3) {
+        if (have_blk) return spmm_blk_launch<T, MODE>(st, blk, lay.Dpad, val_blk.p, in, outp, Fp, X2p, c1, c2, c3, nullptr);
+        return spmm_launch<T, MODE>(st, K, lay, nblk, indptr, col, val, in, outp, Fp, X2p, c1, c2, c3, nullptr);
+    }
 
     // V <- V * F twice with F from the Gram matrix: Cholesky-QR (cheap) and, when the block is too
     // ill-conditioned for it, the eigen-based factor D Q Lambda^{-1/2}; columns orthonormal to rounding
@@ -217,6 +233,10 @@ template <typename T> struct Factorizer {
         if (rho_part.n < (size_t)MAX_PART) MMW_TRY(rho_part.alloc(MAX_PART));
         MMW_TRY(dw.ensure(b, 16));
         if (kt) MMW_TRY(kt->begin(KT_FACTOR));
+        if (have_blk) {  // matrix values once into the blocked order (padding entries stay zero)
+            if (val_blk.n < (size_t)nent) MMW_TRY(val_blk.alloc((size_t)nent));
+            hipLaunchKernelGGL((k_gather_blocked<T>), dim3(grid_elems((size_t)nent)), dim3(BLOCK), 0, st, (size_t)nent, bepos, val, val_blk.p);
+        }
         // spectral scale: ||A||_1 >= |lambda|_max
         hipLaunchKernelGGL((k_rowabs<T>), dim3(nblk), dim3(BLOCK), 0, st, K, indptr, col, val, ascale, (const double*)nullptr, 0, rho_part.p);
         std::vector<double> hp(nblk);
@@ -237,7 +257,7 @@ template <typename T> struct Factorizer {
         int degree = 12;  // filter degree schedule 12, 30, 40, 40, ...: few Rayleigh-Ritz / orthonormalisation rounds
         for (; outer < max_outer && !done; ++outer) {
             // ---- Rayleigh-Ritz on span(V)
-            MMW_TRY((spmm_launch<T, SPMM_PLAIN>(st, K, lay, nblk, indptr, col, val, V.p, W.p, nullptr, nullptr, ascale, 0.0, 0.0, nullptr)));
+            MMW_TRY((spmm<SPMM_PLAIN>(lay, nblk, indptr, col, val, V.p, W.p, nullptr, nullptr, ascale, 0.0, 0.0)));
             MMW_TRY(dw.gram(K, b, ld, V.p, W.p, true));
             MMW_TRY(dw.jacobi(b, f32 ? 1e-8 : 1e-13, 30));
             MMW_HIP(hipMemcpyAsync(theta.data(), dw.diag.p, b * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -283,17 +303,17 @@ template <typename T> struct Factorizer {
             const double a0 = std::max(mu_top, rho * rho * 1e-30);
             double sigma1 = e / (a0 - cen), sigma = sigma1;
             // Y = sigma1/e (B V - cen V): T1 = A V (already W); Ycur = c1 * A W + c2 * V
-            MMW_TRY((spmm_launch<T, SPMM_AXPBY>(st, K, lay, nblk, indptr, col, val, W.p, Y1.p, V.p, V.p, ascale * sigma1 / e, -cen * sigma1 / e, 0.0, nullptr)));
+            MMW_TRY((spmm<SPMM_AXPBY>(lay, nblk, indptr, col, val, W.p, Y1.p, V.p, V.p, ascale * sigma1 / e, -cen * sigma1 / e, 0.0)));
             // V = previous, Y1 = current
             T* prev = V.p;
             T* cur = Y1.p;
             T* nxt = Y2.p;
             for (int i = 2; i <= degree; ++i) {
                 const double sigma2 = 1.0 / (2.0 / sigma1 - sigma);
-                MMW_TRY((spmm_launch<T, SPMM_PLAIN>(st, K, lay, nblk, indptr, col, val, cur, W.p, nullptr, nullptr, ascale, 0.0, 0.0, nullptr)));
+                MMW_TRY((spmm<SPMM_PLAIN>(lay, nblk, indptr, col, val, cur, W.p, nullptr, nullptr, ascale, 0.0, 0.0)));
                 // nxt = 2 sigma2/e (A W - cen cur) - sigma sigma2 prev
-                MMW_TRY((spmm_launch<T, SPMM_AXPBY>(st, K, lay, nblk, indptr, col, val, W.p, nxt, cur, prev, ascale * 2.0 * sigma2 / e,
-                                                    -cen * 2.0 * sigma2 / e, -sigma * sigma2, nullptr)));
+                MMW_TRY((spmm<SPMM_AXPBY>(lay, nblk, indptr, col, val, W.p, nxt, cur, prev, ascale * 2.0 * sigma2 / e, -cen * 2.0 * sigma2 / e,
+                                          -sigma * sigma2)));
                 T* t = prev;
                 prev = cur;
                 cur = nxt;

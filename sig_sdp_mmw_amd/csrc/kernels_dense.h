@@ -330,6 +330,14 @@ __global__ __launch_bounds__(BLOCK) void k_export_factor(int K, int rank, int ld
         out[o] = (double)V[r * ld + sel[c]] * sc[c];
     }
 }
+// dst[i] = src[map[i]] (0 where map[i] < 0): CSR-ordered values into the blocked traversal order
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_gather_blocked(size_t n, const int* __restrict__ map, const T* __restrict__ src, T* __restrict__ dst) {
+    for (size_t o = (size_t)blockIdx.x * BLOCK + threadIdx.x; o < n; o += (size_t)gridDim.x * BLOCK) {
+        const int m = map[o];
+        dst[o] = m >= 0 ? src[m] : T(0);
+    }
+}
 // dst = src * s
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_scaled_copy(size_t n, const T* __restrict__ src, double s, T* __restrict__ dst) {

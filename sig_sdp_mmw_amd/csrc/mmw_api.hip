@@ -164,6 +164,7 @@ template <typename T> struct Solver final : mmw_solver {
             sddmm_blk = true;
         }
         MMW_HIP(hipStreamSynchronize(st));
+        extras.fac.set_blocking(blkdev(), b_bepos.p, HB.nent);
         return eng.enable_blocking(blkdev(), lval_blk.p);
     }
 
