@@ -20,7 +20,7 @@ namespace mmw {
 
 constexpr int BLK_UNION = 448;      // rows of the staged tile (448 x 256 B = 112 KiB of the 160 KiB LDS)
 constexpr int BLK_ROWS = 64;        // max matrix rows per block
-constexpr int BLK_META_BYTES = 40960;  // LDS bytes for the block's (local index, value) entries
+constexpr int BLK_META_BYTES = 39936;  // LDS bytes for the block's (local index, value) entries
 constexpr int BLK_CHUNK = 16;       // entries per wave step (4 lane groups x 4); rows are padded to this
 
 struct HostBlocking {
@@ -41,6 +41,11 @@ struct HostBlocking {
     std::vector<uint16_t> sd_la, sd_lb; // local index of the row / of the column in the block's union
     std::vector<int32_t> sd_epos;       // original CSR position of the entry
     int sd_max = 0;                     // largest per-block entry count
+    // one 8-int record per row block {q0, rows, m0, entries, un0, union size, chunks, 0} and the union's column
+    // ids at a fixed stride (BLK_UNION per block, padded with the block's first column): a workgroup finds
+    // everything it needs from its block id alone, without a chain of dependent index loads
+    std::vector<int32_t> desc;
+    std::vector<int32_t> un_fixed;
     int nb() const { return (int)blk_rowptr.size() - 1; }
 };
 
@@ -202,6 +207,16 @@ inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& i
         B.sd_max = std::max(B.sd_max, B.sd_ptr[b + 1] - B.sd_ptr[b]);
     }
     B.nent = w;
+    B.desc.assign((size_t)B.nb() * 8, 0);
+    B.un_fixed.assign((size_t)B.nb() * BLK_UNION, 0);
+    for (int b = 0; b < B.nb(); ++b) {
+        const int q0 = B.blk_rowptr[b], q1 = B.blk_rowptr[b + 1];
+        const int nun = B.un_ptr[b + 1] - B.un_ptr[b];
+        int32_t* d = &B.desc[(size_t)b * 8];
+        d[0] = q0; d[1] = q1 - q0; d[2] = B.bptr[q0]; d[3] = B.bptr[q1] - B.bptr[q0]; d[4] = B.un_ptr[b]; d[5] = nun;
+        d[6] = (B.bptr[q1] - B.bptr[q0]) / BLK_CHUNK;
+        for (int u = 0; u < BLK_UNION; ++u) B.un_fixed[(size_t)b * BLK_UNION + u] = B.un_cols[B.un_ptr[b] + (u < nun ? u : 0)];
+    }
     B.reuse = B.un_cols.empty() ? 0.0 : (double)nnz / (double)B.un_cols.size();
     B.usable = B.reuse >= 2.0;
 }

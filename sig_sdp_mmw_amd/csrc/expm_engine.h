@@ -55,10 +55,11 @@ inline int spmm_blk_launch(hipStream_t st, const BlkDev& B, int Dpad, const T* v
     constexpr int CT = BLK_TILE_BYTES / (int)sizeof(T);
     const int ntiles = (Dpad + CT - 1) / CT;
     int tpw = (int)((double)B.nb * ntiles / (3.0 * 256.0) + 0.5);  // ~3 workgroups per CU over the launch
+    if (getenv("MMW_TPW")) tpw = atoi(getenv("MMW_TPW"));
     tpw = tpw < 1 ? 1 : (tpw > ntiles ? ntiles : tpw);
     const int total = B.nb * ((ntiles + tpw - 1) / tpw);
     const int per = (total + 7) / 8;
-    const size_t sh = (size_t)BLK_UNION_ROWS * BLK_TILE_BYTES + BLK_META_LDS + (size_t)BLK_WAVES * CT * sizeof(double);
+    const size_t sh = (size_t)BLK_UNION_ROWS * BLK_TILE_BYTES + BLK_META_LDS + BLK_ROWINFO_LDS + (size_t)BLK_WAVES * CT * sizeof(double);
     static bool attr_set = false;  // per (T, MODE) instantiation
     if (!attr_set) {
         MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_blk<T, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));

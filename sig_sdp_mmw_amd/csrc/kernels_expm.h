@@ -182,12 +182,15 @@ struct BlkDev {
     const int* bptr;          // [K+1] blocked entry ranges by position (multiples of 16)
     const unsigned short* lidx;
     const unsigned short* self_li;  // [K] by position: local index of the row itself (its diagonal entry)
+    const int* desc;          // [nb][8] {q0, rows, m0, entries, un0, union size, chunks, 0}
+    const int* un_fixed;      // [nb][BLK_UNION_ROWS] union column ids at a fixed stride
 };
 constexpr int BLK_THREADS = 1024;
 constexpr int BLK_WAVES = BLK_THREADS / WAVE;
 constexpr int BLK_TILE_BYTES = 256;
 constexpr int BLK_UNION_ROWS = 448;
-constexpr int BLK_META_LDS = 40960;
+constexpr int BLK_META_LDS = 39936;   // staged (offset, value) entries
+constexpr int BLK_ROWINFO_LDS = 1024;  // 64 rows x {first entry, chunks, output row, own staged row}
 template <typename T> struct BlkMeta {  // one staged entry
     unsigned int li;
     T v;
@@ -216,7 +219,6 @@ __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, in
                                                           unsigned long long* __restrict__ stamps) {
     constexpr int VEC = V16<T>::N;
     constexpr int CT = BLK_TILE_BYTES / (int)sizeof(T);  // columns per tile
-    constexpr int dbg = 0;
 #define MMW_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     MMW_STAMP(0);
     if (plan) {
@@ -228,7 +230,8 @@ __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, in
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* tile = reinterpret_cast<T*>(smem_raw);                                                        // [BLK_UNION_ROWS][CT]
     BlkMeta<T>* meta = reinterpret_cast<BlkMeta<T>*>(smem_raw + (size_t)BLK_UNION_ROWS * BLK_TILE_BYTES);  // [entries]
-    double* shdot = reinterpret_cast<double*>(smem_raw + (size_t)BLK_UNION_ROWS * BLK_TILE_BYTES + BLK_META_LDS);  // [BLK_WAVES][CT]
+    int4* rowinfo = reinterpret_cast<int4*>(smem_raw + (size_t)BLK_UNION_ROWS * BLK_TILE_BYTES + BLK_META_LDS);  // [64]
+    double* shdot = reinterpret_cast<double*>(smem_raw + (size_t)BLK_UNION_ROWS * BLK_TILE_BYTES + BLK_META_LDS + BLK_ROWINFO_LDS);  // [BLK_WAVES][CT]
     // XCD-aware id: consecutive ids of one XCD walk consecutive row blocks of one tile group
     const int ngroups = (ntiles + tpw - 1) / tpw;
     const int total = B.nb * ngroups;
@@ -238,19 +241,18 @@ __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, in
     const int tg = id / B.nb, rb = id - tg * B.nb;
     const int t0 = tg * tpw, t1 = min(ntiles, t0 + tpw);
     const int l16 = threadIdx.x & 15;
-    const int q0 = B.rowptr[rb], q1 = B.rowptr[rb + 1];
-    const int m0 = B.bptr[q0], nmeta = B.bptr[q1] - m0;
-    const int un0 = B.un_ptr[rb], nun = B.un_ptr[rb + 1] - un0;
+    // everything about the block from one record at a fixed address (no chain of dependent index loads)
+    const int* dsc = B.desc + (size_t)rb * 8;
+    const int q0 = dsc[0], q1 = q0 + dsc[1];
+    const int m0 = dsc[2], nmeta = dsc[3];
+    const int nun = dsc[5];
     const int u0 = threadIdx.x >> 4;
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int g = lane >> 4;  // lane group = one nonzero per LDS read
     // this thread's share of the union (same rows for every tile)
-    size_t gbase[NG];
+    unsigned gbase[NG];  // element offsets of the union rows (K * Dpad < 2^32)
 #pragma unroll
-    for (int j = 0; j < NG; ++j) {
-        const int u = u0 + j * RPP;
-        gbase[j] = u < nun ? (size_t)B.un_cols[un0 + u] * Dpad : (size_t)0;
-    }
+    for (int j = 0; j < NG; ++j) gbase[j] = (unsigned)B.un_fixed[(size_t)rb * BLK_UNION_ROWS + u0 + j * RPP] * (unsigned)Dpad;
     T x[NG][VEC];
     auto gather = [&](int t) {
         const int c = t * CT + l16 * VEC;
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, in
         for (int j = 0; j < NG; ++j) {
 #pragma unroll
             for (int v = 0; v < VEC; ++v) x[j][v] = T(0);
-            if (u0 + j * RPP < nun && c < Dpad && !(dbg & 1)) load16(U + gbase[j] + c, x[j]);
+            if (u0 + j * RPP < nun && c < Dpad) load16(U + (size_t)gbase[j] + c, x[j]);
         }
     };
     auto deposit = [&]() {
@@ -267,12 +269,37 @@ __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, in
             if (u0 + j * RPP < nun) store16(tile + (size_t)(u0 + j * RPP) * CT + l16 * VEC, x[j]);
     };
     MMW_STAMP(1);
+    // the block's entries, once for all its tiles: requested before the gathers so they land first
+    constexpr int NM = (BLK_META_LDS / (int)sizeof(BlkMeta<T>) + BLK_THREADS - 1) / BLK_THREADS;
+    unsigned mli[NM];
+    T mv[NM];
+#pragma unroll
+    for (int k = 0; k < NM; ++k) {
+        const int i = threadIdx.x + k * BLK_THREADS;
+        mli[k] = 0;
+        mv[k] = T(0);
+        if (i < nmeta) {
+            mli[k] = (unsigned)B.lidx[m0 + i] * BLK_TILE_BYTES;  // byte offset of the staged row
+            mv[k] = val_blk[m0 + i];
+        }
+    }
+    int4 ri = make_int4(0, 0, 0, 0);  // per-row bookkeeping, fetched once per workgroup (not per tile)
+    if ((int)threadIdx.x < q1 - q0) {
+        const int q = q0 + threadIdx.x;
+        const int b0 = B.bptr[q];
+        ri = make_int4(b0 - m0, (B.bptr[q + 1] - b0) >> 4, B.order[q], (int)B.self_li[q] * BLK_TILE_BYTES);
+    }
     gather(t0);
-    for (int i = threadIdx.x; i < nmeta; i += BLK_THREADS) {  // the block's entries, once for all its tiles
-        BlkMeta<T> e;
-        e.li = (unsigned)B.lidx[m0 + i] * BLK_TILE_BYTES;  // byte offset of the staged row
-        e.v = val_blk[m0 + i];
-        meta[i] = e;
+    if ((int)threadIdx.x < q1 - q0) rowinfo[threadIdx.x] = ri;
+#pragma unroll
+    for (int k = 0; k < NM; ++k) {
+        const int i = threadIdx.x + k * BLK_THREADS;
+        if (i < nmeta) {
+            BlkMeta<T> e;
+            e.li = mli[k];
+            e.v = mv[k];
+            meta[i] = e;
+        }
     }
     MMW_STAMP(2);
     deposit();
@@ -283,33 +310,50 @@ __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, in
         if (t + 1 < t1) gather(t + 1);  // next tile's rows fly while this tile is consumed from LDS
         const int col0 = t * CT;
         const bool colok = col0 + l16 * VEC < Dpad;
-        double dot[VEC];
+        T dot[VEC];  // alpha numerators of this wave's (few) rows for this tile; widened when they leave the wave
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) dot[v] = 0.0;
+        for (int v = 0; v < VEC; ++v) dot[v] = T(0);
         for (int q = q0 + wib; q < q1; q += BLK_WAVES) {
             T acc[VEC];
 #pragma unroll
             for (int v = 0; v < VEC; ++v) acc[v] = T(0);
             // wave-uniform row extent -> scalar loop control, no divergence in the hot loop
-            const int beg = __builtin_amdgcn_readfirstlane(B.bptr[q]) - m0;
-            const int nch = (dbg & 2) ? 0 : (__builtin_amdgcn_readfirstlane(B.bptr[q + 1]) - m0 - beg) >> 4;
+            const int4 rinfo = rowinfo[q - q0];
+            const int beg = __builtin_amdgcn_readfirstlane(rinfo.x);
+            const int nch = __builtin_amdgcn_readfirstlane(rinfo.y);
             const BlkMeta<T>* mp = meta + beg + 4 * g;
             const char* tbase = reinterpret_cast<const char*>(tile) + l16 * 16;
-            unsigned li[4];
-            T vv[4];
-            if (nch > 0) load_meta4(mp, li, vv);
-            for (int c = 0; c < nch; ++c) {
+            // two register sets (A/B) alternate: the entries of chunk k+1 are requested BEFORE the staged rows of
+            // chunk k, so the single wait that covers the rows also covers them and the next step can issue at once
+            unsigned liA[4], liB[4];
+            T vA[4], vB[4];
+            if (nch > 0) load_meta4(mp, liA, vA);
+            int c = 0;
+            for (; c + 1 < nch; c += 2) {
                 T xx[4][VEC];
+                load_meta4(mp + 16 * (c + 1), liB, vB);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) load16(reinterpret_cast<const T*>(tbase + li[u]), xx[u]);
-                T cv[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) cv[u] = vv[u];
-                if (c + 1 < nch) load_meta4(mp + 16 * (c + 1), li, vv);  // next chunk's entries while this one's rows arrive
+                for (int u = 0; u < 4; ++u) load16(reinterpret_cast<const T*>(tbase + liA[u]), xx[u]);
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) acc[v] += cv[u] * xx[u][v];
+                    for (int v = 0; v < VEC; ++v) acc[v] += vA[u] * xx[u][v];
+                if (c + 2 < nch) load_meta4(mp + 16 * (c + 2), liA, vA);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) load16(reinterpret_cast<const T*>(tbase + liB[u]), xx[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[v] += vB[u] * xx[u][v];
+            }
+            if (c < nch) {
+                T xx[4][VEC];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) load16(reinterpret_cast<const T*>(tbase + liA[u]), xx[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[v] += vA[u] * xx[u][v];
             }
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
@@ -317,7 +361,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, in
                 acc[v] += __shfl_xor(acc[v], 32, WAVE);
             }
             if (g == 0 && colok) {
-                const int row = B.order[q];
+                const int row = rinfo.z;
                 const size_t off = (size_t)row * Dpad + col0 + l16 * VEC;
                 T o[VEC];
                 if (MODE == SPMM_PLAIN) {
@@ -325,11 +369,11 @@ __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, in
                     for (int v = 0; v < VEC; ++v) o[v] = (T)(ascale * (double)acc[v]);
                 } else if (MODE == SPMM_LANCZOS) {
                     T u[VEC];
-                    load16(tile + (size_t)B.self_li[q] * CT + l16 * VEC, u);  // U[row] is in the staged union (diagonal entry)
+                    load16(reinterpret_cast<const T*>(tbase + rinfo.w), u);  // U[row] is in the staged union (diagonal entry)
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
                         o[v] = (T)(ascale * (double)acc[v]);
-                        dot[v] += (double)u[v] * (double)o[v];
+                        dot[v] += u[v] * o[v];
                     }
                 } else if (MODE == SPMM_AXPBY) {
                     T f[VEC], x2[VEC];
@@ -339,7 +383,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, in
                     for (int v = 0; v < VEC; ++v) o[v] = (T)(ascale * (double)acc[v] + shift * (double)f[v] + inv_k * (double)x2[v]);
                 } else {
                     T u[VEC], f[VEC];
-                    load16(tile + (size_t)B.self_li[q] * CT + l16 * VEC, u);
+                    load16(reinterpret_cast<const T*>(tbase + rinfo.w), u);
                     load16(F + off, f);
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
@@ -354,7 +398,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, in
         if (MODE == SPMM_LANCZOS) {
             if (g == 0)
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) shdot[wib * CT + l16 * VEC + v] = dot[v];
+                for (int v = 0; v < VEC; ++v) shdot[wib * CT + l16 * VEC + v] = (double)dot[v];
         }
         if (t == t0) MMW_STAMP(5);
         __syncthreads();  // every wave is done with this tile (and shdot is complete)

@@ -298,13 +298,10 @@ __global__ __launch_bounds__(BLK_THREADS) void k_sddmm_blk(BlkDev B, SdDev S, Pa
     if (rb >= B.nb) return;
     const int l16 = threadIdx.x & 15;
     const int u0 = threadIdx.x >> 4;
-    const int un0 = B.un_ptr[rb], nun = B.un_ptr[rb + 1] - un0;
-    size_t gbase[NG];
+    const int nun = B.desc[(size_t)rb * 8 + 5];
+    unsigned gbase[NG];  // element offsets of the union rows (K * Dpad < 2^32)
 #pragma unroll
-    for (int j = 0; j < NG; ++j) {
-        const int u = u0 + j * RPP;
-        gbase[j] = u < nun ? (size_t)B.un_cols[un0 + u] * Dpad : (size_t)0;
-    }
+    for (int j = 0; j < NG; ++j) gbase[j] = (unsigned)B.un_fixed[(size_t)rb * BLK_UNION_ROWS + u0 + j * RPP] * (unsigned)Dpad;
     T x[NG][VEC];
     auto gather = [&](int t) {
         const int c = t * CT + l16 * VEC;
@@ -312,7 +309,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_sddmm_blk(BlkDev B, SdDev S, Pa
         for (int j = 0; j < NG; ++j) {
 #pragma unroll
             for (int v = 0; v < VEC; ++v) x[j][v] = T(0);
-            if (u0 + j * RPP < nun && c < Dpad) load16(Yb + gbase[j] + c, x[j]);
+            if (u0 + j * RPP < nun && c < Dpad) load16(Yb + (size_t)gbase[j] + c, x[j]);
         }
     };
     auto deposit = [&]() {

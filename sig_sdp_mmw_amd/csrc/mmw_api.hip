@@ -51,7 +51,7 @@ template <typename T> struct Solver final : mmw_solver {
     HostBlocking HB;
     DevBuf<int> b_rowptr, b_order, b_unptr, b_uncols, b_bptr, b_bpos, b_bepos;
     DevBuf<unsigned short> b_lidx, b_selfli, b_sdla, b_sdlb;
-    DevBuf<int> b_sdptr, b_sdepos;
+    DevBuf<int> b_sdptr, b_sdepos, b_desc, b_unfixed;
     bool sddmm_blk = false;
     DevBuf<T> lval_blk;
     int blocking_mode = 1;  // 1: use when profitable, 0: never
@@ -143,7 +143,7 @@ template <typename T> struct Solver final : mmw_solver {
     BlkDev blkdev() const {
         BlkDev B;
         B.nb = HB.nb(); B.rowptr = b_rowptr.p; B.order = b_order.p; B.un_ptr = b_unptr.p; B.un_cols = b_uncols.p;
-        B.bptr = b_bptr.p; B.lidx = b_lidx.p; B.self_li = b_selfli.p;
+        B.bptr = b_bptr.p; B.lidx = b_lidx.p; B.self_li = b_selfli.p; B.desc = b_desc.p; B.un_fixed = b_unfixed.p;
         return B;
     }
     int setup_blocking() {
@@ -154,7 +154,7 @@ template <typename T> struct Solver final : mmw_solver {
         if (!HB.usable) return MMW_OK;
         MMW_TRY(b_rowptr.upload(HB.blk_rowptr, st)); MMW_TRY(b_order.upload(HB.order, st)); MMW_TRY(b_unptr.upload(HB.un_ptr, st));
         MMW_TRY(b_uncols.upload(HB.un_cols, st)); MMW_TRY(b_bptr.upload(HB.bptr, st)); MMW_TRY(b_bpos.upload(HB.bpos, st));
-        MMW_TRY(b_bepos.upload(HB.bepos, st)); MMW_TRY(b_lidx.upload(HB.lidx, st)); MMW_TRY(b_selfli.upload(HB.self_li, st));
+        MMW_TRY(b_bepos.upload(HB.bepos, st)); MMW_TRY(b_lidx.upload(HB.lidx, st)); MMW_TRY(b_selfli.upload(HB.self_li, st)); MMW_TRY(b_desc.upload(HB.desc, st)); MMW_TRY(b_unfixed.upload(HB.un_fixed, st));
         MMW_TRY(lval_blk.alloc((size_t)HB.nent));
         if (HB.sd_max <= SD_ROUNDS * BLK_THREADS) {
             MMW_TRY(b_sdptr.upload(HB.sd_ptr, st)); MMW_TRY(b_sdla.upload(HB.sd_la, st)); MMW_TRY(b_sdlb.upload(HB.sd_lb, st));
@@ -202,14 +202,19 @@ template <typename T> struct Solver final : mmw_solver {
         hipEvent_t e0, e1;
         MMW_HIP(hipEventCreate(&e0));
         MMW_HIP(hipEventCreate(&e1));
-        int rc = eng.template launch_spmm<SPMM_PLAIN>(eng.start_block(), eng.Tm.p, nullptr, 0.5, 0.0, 1.0);  // warm
+        const bool lz = getenv("MMW_BENCH_LANCZOS") != nullptr;  // time the Lanczos epilogue (alpha partials) instead of the plain product
+        auto one = [&]() {
+            return lz ? eng.template launch_spmm<SPMM_LANCZOS>(eng.start_block(), eng.Tm.p, nullptr, 0.5, 0.0, 1.0)
+                      : eng.template launch_spmm<SPMM_PLAIN>(eng.start_block(), eng.Tm.p, nullptr, 0.5, 0.0, 1.0);
+        };
+        int rc = one();  // warm
         MMW_HIP(hipEventRecord(e0, st));
-        for (int r = 0; r < reps && rc == MMW_OK; ++r) rc = eng.template launch_spmm<SPMM_PLAIN>(eng.start_block(), eng.Tm.p, nullptr, 0.5, 0.0, 1.0);
+        for (int r = 0; r < reps && rc == MMW_OK; ++r) rc = one();
         MMW_HIP(hipEventRecord(e1, st));
         MMW_HIP(hipStreamSynchronize(st));
         if (want_stamps) {
             g_blk_stamps = stamps.p;
-            rc = eng.template launch_spmm<SPMM_PLAIN>(eng.start_block(), eng.Tm.p, nullptr, 0.5, 0.0, 1.0);
+            rc = one();
             g_blk_stamps = nullptr;
             std::vector<unsigned long long> h((size_t)16 * 8192);
             MMW_HIP(hipMemcpyAsync(h.data(), stamps.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
