@@ -104,6 +104,20 @@ template <typename T> struct DenseWork {
     // Jacobi of G (b x b) -> eigenvalues in `diag`, eigenvectors in Q (one launch per round, ping-pong buffers)
     int jacobi(int b, double rel_tol, int max_sweeps, int* sweeps_done = nullptr) {
         const int n = (b % 2 == 0) ? b : b + 1;
+        if (b <= JAC_LDS_MAX) {  // small: the whole eigensolve in one launch, matrices in LDS
+            const size_t sh = ((size_t)2 * b * b + n + 2) * sizeof(double);
+            static bool attr = false;
+            if (!attr) {
+                MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jacobi_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)(((size_t)2 * JAC_LDS_MAX * JAC_LDS_MAX + JAC_LDS_MAX + 4) * sizeof(double))));
+                attr = true;
+            }
+            hipLaunchKernelGGL(k_jacobi_lds, dim3(1), dim3(1024), sh, st, b, G.p, diag.p, Q.p, rel_tol, max_sweeps, (int*)nullptr);
+            MMW_HIP(hipGetLastError());
+            calls_total += 1;
+            if (sweeps_done) *sweeps_done = 0;
+            return MMW_OK;
+        }
         if (G2.n < (size_t)b * b) { MMW_TRY(G2.alloc((size_t)bcap * bcap)); MMW_TRY(Q3.alloc((size_t)bcap * bcap)); }
         hipLaunchKernelGGL(k_set_eye, dim3(grid_elems((size_t)b * b)), dim3(BLOCK), 0, st, b, Q.p);
         const int half = n / 2;
@@ -219,7 +233,7 @@ template <typename T> struct Factorizer {
         if (rank < 1 || rank >= K + 1) return fail(MMW_ERR_ARG, "mmw_factor: rank must be in [1, K]");
         const bool f32 = sizeof(T) == 4;
         const double tol = f32 ? 2e-5 : 1e-9;
-        int b = std::min(K, rank + std::max(16, rank / 4));
+        int b = std::min(K, rank + std::max(12, rank / 5));
         if (K <= 384 || 4 * b >= 3 * K) b = K;  // small or nearly full: one exact Rayleigh-Ritz on the whole space
         BlockLayout lay;
         std::string err;

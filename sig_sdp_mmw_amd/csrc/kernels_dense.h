@@ -189,6 +189,89 @@ __global__ __launch_bounds__(BLOCK) void k_jacobi_round(int b, int n, int r, con
         Qout[(size_t)x * b + qj] = a * sj + d * cj;
     }
 }
+// ---- whole Jacobi eigensolve of a small matrix (b <= JAC_LDS_MAX) in ONE launch: H and Q live in LDS, rounds are
+// separated by workgroup barriers instead of kernel boundaries.  Same rotations and ordering as k_jacobi_round.
+constexpr int JAC_LDS_MAX = 96;
+__global__ __launch_bounds__(1024) void k_jacobi_lds(int b, const double* __restrict__ Hin, double* __restrict__ diag, double* __restrict__ Qout,
+                                                     double rel_tol, int max_sweeps, int* __restrict__ sweeps_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* H = reinterpret_cast<double*>(smem_raw);  // [b][b]
+    double* Q = H + (size_t)b * b;                    // [b][b]
+    double* cs = Q + (size_t)b * b;                   // [n]
+    __shared__ double red[32];
+    __shared__ int stop;
+    const int n = (b % 2 == 0) ? b : b + 1, half = n / 2;
+    for (int o = threadIdx.x; o < b * b; o += blockDim.x) {
+        H[o] = Hin[o];
+        Q[o] = (o / b == o % b) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    int sw = 0;
+    for (; sw < max_sweeps; ++sw) {
+        // off-diagonal norm and diagonal scale
+        double s = 0.0, d = 0.0;
+        for (int o = threadIdx.x; o < b * b; o += blockDim.x) {
+            const int i = o / b, j = o % b;
+            const double h = H[o];
+            if (i != j) s += h * h;
+            else d = fabs(h) > d ? fabs(h) : d;
+        }
+        s = wave_sum(s);
+        d = wave_max(d);
+        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s; red[16 + (threadIdx.x >> 6)] = d; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double ts = 0.0, td = 0.0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { ts += red[w]; td = red[16 + w] > td ? red[16 + w] : td; }
+            stop = !(sqrt(ts) > rel_tol * td * sqrt((double)b)) || b < 2;
+        }
+        __syncthreads();
+        if (stop) break;
+        for (int r = 0; r < n - 1; ++r) {
+            for (int i = threadIdx.x; i < half; i += blockDim.x) {
+                int p, q;
+                jacobi_pair(n, r, i, p, q);
+                double c, sn;
+                jacobi_cs(H, b, p, q, c, sn);
+                cs[2 * i] = c;
+                cs[2 * i + 1] = sn;
+            }
+            __syncthreads();
+            for (int o = threadIdx.x; o < half * half; o += blockDim.x) {
+                const int i = o / half, j = o % half;
+                int pi, qi, pj, qj;
+                jacobi_pair(n, r, i, pi, qi);
+                jacobi_pair(n, r, j, pj, qj);
+                const double ci = cs[2 * i], si = cs[2 * i + 1], cj = cs[2 * j], sj = cs[2 * j + 1];
+                const bool qi_ok = qi < b, qj_ok = qj < b;
+                double h00 = H[pi * b + pj];
+                double h01 = qj_ok ? H[pi * b + qj] : 0.0;
+                double h10 = qi_ok ? H[qi * b + pj] : 0.0;
+                double h11 = (qi_ok && qj_ok) ? H[qi * b + qj] : 0.0;
+                const double t00 = ci * h00 - si * h10, t01 = ci * h01 - si * h11;
+                const double t10 = si * h00 + ci * h10, t11 = si * h01 + ci * h11;
+                H[pi * b + pj] = t00 * cj - t01 * sj;
+                if (qj_ok) H[pi * b + qj] = t00 * sj + t01 * cj;
+                if (qi_ok) H[qi * b + pj] = t10 * cj - t11 * sj;
+                if (qi_ok && qj_ok) H[qi * b + qj] = t10 * sj + t11 * cj;
+            }
+            for (int o = threadIdx.x; o < b * half; o += blockDim.x) {
+                const int x = o / half, j = o % half;
+                int pj, qj;
+                jacobi_pair(n, r, j, pj, qj);
+                if (qj >= b) continue;
+                const double cj = cs[2 * j], sj = cs[2 * j + 1];
+                const double a = Q[x * b + pj], dd = Q[x * b + qj];
+                Q[x * b + pj] = a * cj - dd * sj;
+                Q[x * b + qj] = a * sj + dd * cj;
+            }
+            __syncthreads();
+        }
+    }
+    for (int o = threadIdx.x; o < b * b; o += blockDim.x) Qout[o] = Q[o];
+    for (int i = threadIdx.x; i < b; i += blockDim.x) diag[i] = H[i * b + i];
+    if (threadIdx.x == 0 && sweeps_out) *sweeps_out = sw;
+}
 // ---- Cholesky G = L L^T in place (lower triangle), one workgroup; *flag = 1 when a pivot is not positive
 __global__ __launch_bounds__(1024) void k_cholesky(int b, double* __restrict__ G, int* __restrict__ flag) {
     __shared__ double dj;

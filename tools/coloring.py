@@ -1,7 +1,7 @@
 """Developer tool: wall-clock of the whole binary search to a converged colouring (run on the GPU box)."""
-import sys, time, json
+import os, sys, time, json
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import WORKLOADS, make_state
 from sig_sdp_mmw_amd.binary_search import binary_search_relaxation
 from sig_sdp_mmw_amd.mmw import mmw

@@ -1,7 +1,7 @@
 """Developer tool: time the generic and the blocked SpMM on a bench workload (run on the GPU box)."""
-import sys, time
+import os, sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import WORKLOADS, make_state, first_midpoint
 from sig_sdp_mmw_amd import _lib
 

@@ -1,7 +1,7 @@
 """Developer tool: SpMM time vs block width D on the bench graph (run on the GPU box)."""
-import sys
+import os, sys
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import WORKLOADS, make_state
 from sig_sdp_mmw_amd import _lib
 name = sys.argv[1] if len(sys.argv) > 1 else "journal-1pct"
