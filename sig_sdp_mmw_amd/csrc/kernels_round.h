@@ -106,52 +106,124 @@ __global__ __launch_bounds__(BLOCK) void k_slot_pref(int K, int Z, const double*
 //   (a) the interference already accumulated at k stays within h_max[k],
 //   (b) adding k's emission keeps every current member n of the slot that k reaches within h_max[n],
 //   (c) no current member shares an access point with k.
-// gain_sum[z][n] accumulates S[k'][n] over the members k' of slot z in assignment order, exactly like
-// the reference's dense row adds (sdp_solver.py:94) restricted to the nonzeros.
-__global__ __launch_bounds__(BLOCK) void k_greedy(int K, int Z, const int* __restrict__ order, const int* __restrict__ pref_all,
-                                                  const int* __restrict__ so_indptr, const int* __restrict__ so_indices,
-                                                  const double* __restrict__ so_data, const int* __restrict__ q_indptr,
-                                                  const int* __restrict__ q_indices, const double* __restrict__ h_max,
-                                                  double* __restrict__ gain_all, int* __restrict__ slot_all, int* __restrict__ rem) {
+// gain_sum[n][z] accumulates S[k'][n] over the members k' of slot z in assignment order, exactly like
+// the reference's dense row adds (sdp_solver.py:94) restricted to the nonzeros (user-major layout: the
+// Z sums of one user are contiguous).
+// The loop is sequential in the users, so its speed is the length of the dependent-load chain per user.
+// Everything that does not depend on earlier assignments (the user's id, neighbour lists, gains, thresholds,
+// preference row) is fetched one user ahead into a double-buffered LDS record; what remains on the chain is
+// slot[n] (LDS when K fits) -> gain_sum[n][slot[n]].
+struct GreedyLds {          // one prefetched user
+    int k, deg, qdeg, pad;
+};
+template <bool SLOT_LDS>
+__global__ __launch_bounds__(BLOCK) void k_greedy(int K, int Z, int maxdeg, int maxq, const int* __restrict__ order,
+                                                  const int* __restrict__ pref_all, const int* __restrict__ so_indptr,
+                                                  const int* __restrict__ so_indices, const double* __restrict__ so_data,
+                                                  const int* __restrict__ q_indptr, const int* __restrict__ q_indices,
+                                                  const double* __restrict__ h_max, double* __restrict__ gain_all,
+                                                  int* __restrict__ slot_all, int* __restrict__ rem) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    int* bad = reinterpret_cast<int*>(smem_raw);  // [Z]
+    // layout: [2] x { nid[maxdeg] int, nval[maxdeg] f64, nh[maxdeg] f64, qid[maxq] int, pref[Z] int }, bad[Z] int, slot[K] int (optional)
+    char* sp = smem_raw;
+    double* nval[2]; double* nh[2]; int* nid[2]; int* qid[2]; int* prf[2];
+    for (int s2 = 0; s2 < 2; ++s2) { nval[s2] = reinterpret_cast<double*>(sp); sp += (size_t)maxdeg * 8; nh[s2] = reinterpret_cast<double*>(sp); sp += (size_t)maxdeg * 8; }
+    for (int s2 = 0; s2 < 2; ++s2) { nid[s2] = reinterpret_cast<int*>(sp); sp += (size_t)maxdeg * 4; qid[s2] = reinterpret_cast<int*>(sp); sp += (size_t)maxq * 4;
+                                     prf[s2] = reinterpret_cast<int*>(sp); sp += (size_t)Z * 4; }
+    int* bad = reinterpret_cast<int*>(sp); sp += (size_t)Z * 4;
+    int* slot_l = reinterpret_cast<int*>(sp);
+    __shared__ GreedyLds rec[2];
+    __shared__ double hk[2];
     __shared__ int best;
     __shared__ int unassigned;
     const int b = blockIdx.x;
     const int* pref = pref_all + (size_t)b * K * Z;
-    double* gain = gain_all + (size_t)b * Z * K;
-    int* slot = slot_all + (size_t)b * K;
+    double* gain = gain_all + (size_t)b * K * Z;   // [K][Z]
+    int* slot_g = slot_all + (size_t)b * K;
+    int* slot = SLOT_LDS ? slot_l : slot_g;
+    if (SLOT_LDS)
+        for (int i = threadIdx.x; i < K; i += BLOCK) slot_l[i] = -1;
     if (threadIdx.x == 0) unassigned = 0;
+    // everything about user order[kk] that no earlier assignment can change: requested into registers at the top
+    // of the previous user's step (issue), continued after its first barrier (issue2: the loads that need the
+    // neighbour ids), written to the other LDS record at the end of the step (commit) -- never waited for early
+    constexpr int NE = 4;  // neighbour elements per thread: maxdeg <= NE * BLOCK
+    int r_k = 0, r_sb = 0, r_deg = 0, r_qb = 0, r_qdeg = 0;
+    int r_n[NE], r_q[NE], r_p[NE];
+    double r_v[NE], r_h[NE], r_hk = 0.0;
+    auto issue = [&](int kk) {
+        r_k = order[kk];
+        r_sb = so_indptr[r_k]; r_deg = so_indptr[r_k + 1] - r_sb;
+        r_qb = q_indptr[r_k]; r_qdeg = q_indptr[r_k + 1] - r_qb;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = threadIdx.x + i * BLOCK;
+            r_n[i] = e < r_deg ? so_indices[r_sb + e] : 0;
+            r_v[i] = e < r_deg ? so_data[r_sb + e] : 0.0;
+            r_q[i] = e < r_qdeg ? q_indices[r_qb + e] : 0;
+            r_p[i] = e < Z ? pref[(size_t)r_k * Z + e] : 0;
+        }
+        r_hk = h_max[r_k];
+    };
+    auto issue2 = [&]() {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) r_h[i] = (int)(threadIdx.x + i * BLOCK) < r_deg ? h_max[r_n[i]] : 0.0;
+    };
+    auto commit = [&](int s2) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = threadIdx.x + i * BLOCK;
+            if (e < r_deg) { nid[s2][e] = r_n[i]; nval[s2][e] = r_v[i]; nh[s2][e] = r_h[i]; }
+            if (e < r_qdeg) qid[s2][e] = r_q[i];
+            if (e < Z) prf[s2][e] = r_p[i];
+        }
+        if (threadIdx.x == 0) {
+            rec[s2].k = r_k; rec[s2].deg = r_deg; rec[s2].qdeg = r_qdeg;
+            hk[s2] = r_hk;
+        }
+    };
+    issue(0);
+    issue2();
+    commit(0);
+    __syncthreads();
     for (int kk = 0; kk < K; ++kk) {
-        const int k = order[kk];
-        for (int z = threadIdx.x; z < Z; z += BLOCK) bad[z] = gain[(size_t)z * K + k] > h_max[k] ? 1 : 0;
+        const int cur = kk & 1;
+        const bool more = kk + 1 < K;
+        if (more) issue(kk + 1);  // in flight while this user is decided
+        const int k = rec[cur].k, deg = rec[cur].deg, qdeg = rec[cur].qdeg;
+        const double hmk = hk[cur];
+        for (int z = threadIdx.x; z < Z; z += BLOCK) bad[z] = gain[(size_t)k * Z + z] > hmk ? 1 : 0;
         if (threadIdx.x == 0) best = Z;
         __syncthreads();
-        const int sb = so_indptr[k], se = so_indptr[k + 1];
-        for (int e = sb + threadIdx.x; e < se; e += BLOCK) {
-            const int n = so_indices[e];
+        if (more) issue2();
+        for (int e = threadIdx.x; e < deg; e += BLOCK) {
+            const int n = nid[cur][e];
             const int zn = slot[n];
-            if (zn >= 0 && gain[(size_t)zn * K + n] + so_data[e] > h_max[n]) bad[zn] = 1;
+            if (zn >= 0 && gain[(size_t)n * Z + zn] + nval[cur][e] > nh[cur][e]) bad[zn] = 1;
         }
-        for (int e = q_indptr[k] + threadIdx.x; e < q_indptr[k + 1]; e += BLOCK) {
-            const int zn = slot[q_indices[e]];
+        for (int e = threadIdx.x; e < qdeg; e += BLOCK) {
+            const int zn = slot[qid[cur][e]];
             if (zn >= 0) bad[zn] = 1;
         }
         __syncthreads();
         for (int zz = threadIdx.x; zz < Z; zz += BLOCK)
-            if (!bad[pref[(size_t)k * Z + zz]]) {
+            if (!bad[prf[cur][zz]]) {
                 atomicMin(&best, zz);
                 break;  // this thread's later candidates are worse
             }
         __syncthreads();
         const int zz = best;
         if (zz < Z) {
-            const int z = pref[(size_t)k * Z + zz];
-            for (int e = sb + threadIdx.x; e < se; e += BLOCK) gain[(size_t)z * K + so_indices[e]] += so_data[e];
-            if (threadIdx.x == 0) slot[k] = z;
+            const int z = prf[cur][zz];
+            for (int e = threadIdx.x; e < deg; e += BLOCK) gain[(size_t)nid[cur][e] * Z + z] += nval[cur][e];
+            if (threadIdx.x == 0) {
+                slot[k] = z;
+                if (SLOT_LDS) slot_g[k] = z;
+            }
         } else if (threadIdx.x == 0) {
             unassigned++;
         }
+        if (more) commit(cur ^ 1);
         __threadfence_block();
         __syncthreads();
     }

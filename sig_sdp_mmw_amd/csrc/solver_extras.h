@@ -168,8 +168,29 @@ template <typename T> struct Extras {
         if (kt) MMW_TRY(kt->end());
         MMW_HIP(hipGetLastError());
         if (kt) MMW_TRY(kt->begin(KT_GREEDY));
-        hipLaunchKernelGGL(k_greedy, dim3(nb), dim3(BLOCK), (size_t)Z * sizeof(int), st, K, Z, order.p, pref.p, so_indptr.p,
-                           so_indices.p, so_data.p, q_indptr.p, q_indices.p, h_max.p, gain.p, slot.p, rem.p);
+        {
+            int maxdeg = 1, maxq = 1;
+            for (int k = 0; k < K; ++k) {
+                maxdeg = std::max(maxdeg, H->so_indptr[k + 1] - H->so_indptr[k]);
+                maxq = std::max(maxq, H->q_indptr[k + 1] - H->q_indptr[k]);
+            }
+            maxdeg = (maxdeg + 1) / 2 * 2;  // keep the int arrays after the doubles 8-byte aligned
+            if (maxdeg > 4 * BLOCK || maxq > 4 * BLOCK || Z > 4 * BLOCK)
+                return fail(MMW_ERR_ARG, "mmw_round: more than 1024 neighbours / slots per user is not supported by the greedy kernel");
+            const size_t base = (size_t)2 * ((size_t)maxdeg * 20 + (size_t)maxq * 4 + (size_t)Z * 4) + (size_t)Z * 4;
+            const bool slot_lds = base + (size_t)K * 4 <= 150 * 1024;
+            const size_t sh = base + (slot_lds ? (size_t)K * 4 : 0);
+            if (sh > 160 * 1024) return fail(MMW_ERR_ARG, "mmw_round: a user's neighbour list does not fit the greedy kernel's LDS record");
+            if (slot_lds) {
+                MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_greedy<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+                hipLaunchKernelGGL((k_greedy<true>), dim3(nb), dim3(BLOCK), sh, st, K, Z, maxdeg, maxq, order.p, pref.p, so_indptr.p, so_indices.p,
+                                   so_data.p, q_indptr.p, q_indices.p, h_max.p, gain.p, slot.p, rem.p);
+            } else {
+                MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_greedy<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+                hipLaunchKernelGGL((k_greedy<false>), dim3(nb), dim3(BLOCK), sh, st, K, Z, maxdeg, maxq, order.p, pref.p, so_indptr.p, so_indices.p,
+                                   so_data.p, q_indptr.p, q_indices.p, h_max.p, gain.p, slot.p, rem.p);
+            }
+        }
         if (kt) MMW_TRY(kt->end());
         MMW_HIP(hipGetLastError());
         MMW_HIP(hipMemcpyAsync(z_out, slot.p, (size_t)nb * K * sizeof(int), hipMemcpyDeviceToHost, st));
