@@ -117,7 +117,8 @@ template <typename T> struct ExpmEngine {
         if (make_layout(D, V16<T>::N, lay, err) != MMW_OK) return fail(MMW_ERR_ARG, err);
         bs = (size_t)K * lay.Dpad;
         nblk = grid_rows(K);
-        MMW_TRY(U.alloc(bs * (size_t)(MAX_ORDER + 1)));
+        ublocks = 0;
+        MMW_TRY(ensure_blocks(4));  // the basis grows on demand: the MMW loop rarely needs more than 3 vectors
         MMW_TRY(Tm.alloc(bs));
         MMW_TRY(partial.alloc((size_t)MAX_PART * lay.Dpad));
         npart = nblk;
@@ -130,7 +131,22 @@ template <typename T> struct ExpmEngine {
         MMW_HIP(hipMemsetAsync(viol_d.p, 0, sizeof(int), st));
         if (!plan_h) MMW_HIP(hipHostMalloc((void**)&plan_h, sizeof(ExpmPlan)));
         if (use_blk) MMW_TRY(enable_blocking(blk, val_blk));
-        MMW_HIP(hipMemsetAsync(U.p, 0, bs * (size_t)(MAX_ORDER + 1) * sizeof(T), st));
+        return MMW_OK;
+    }
+    int ublocks = 0;  // blocks currently allocated in U
+    // at least `n` basis blocks; contents need not survive (every application rebuilds the basis from block 0,
+    // which the caller fills AFTER asking for the capacity it may need)
+    int ensure_blocks(int n) {
+        if (n <= ublocks) return MMW_OK;
+        if (n > MAX_ORDER + 1) n = MAX_ORDER + 1;
+        DevBuf<T> bigger;
+        MMW_TRY(bigger.alloc(bs * (size_t)n));
+        MMW_HIP(hipMemsetAsync(bigger.p, 0, bs * (size_t)n * sizeof(T), st));
+        if (U.p && ublocks > 0) MMW_HIP(hipMemcpyAsync(bigger.p, U.p, bs * sizeof(T), hipMemcpyDeviceToDevice, st));  // keep the start block
+        MMW_HIP(hipStreamSynchronize(st));
+        std::swap(U.p, bigger.p);
+        std::swap(U.n, bigger.n);
+        ublocks = n;
         return MMW_OK;
     }
     T* start_block() { return U.p; }
@@ -211,6 +227,7 @@ template <typename T> struct ExpmEngine {
         MMW_TRY(make_plan(ascale, trace_part, ntrace, m_launch));
         const int m = m_launch > 0 ? m_launch : last.m;
         const int nsub = m_launch > 0 ? 1 : last.nsub;
+        MMW_TRY(ensure_blocks(std::max(3, m)));
         const ExpmPlan* pd = plan_d.p;
         const int Dpad = lay.Dpad;
         const int gcol = (Dpad + 63) / 64;

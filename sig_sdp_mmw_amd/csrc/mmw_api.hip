@@ -88,7 +88,11 @@ template <typename T> struct Solver final : mmw_solver {
     int init(int dev, int32_t K_, int32_t Z_, int32_t rr, double eta_, int32_t nit_, const int32_t* Sp, const int32_t* Si,
              const double* Sx, const int32_t* Qp, const int32_t* Qi, const double* Qx, const double* h) {
         device = dev;
+        const bool verbose = getenv("MMW_VERBOSE") != nullptr;
+        auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t_0 = tnow();
         std::string err = build_pattern(H, K_, Z_, Sp, Si, Sx, Qp, Qi, Qx, h);
+        const double t_1 = tnow();
         if (!err.empty()) return fail(MMW_ERR_ARG, "mmw_create: " + err);
         K = K_; Z = Z_; rank_radio = rr; eta = eta_; nit = nit_;
         D = Z * rank_radio;
@@ -131,7 +135,10 @@ template <typename T> struct Solver final : mmw_solver {
         eng.max_order = 12;
         eng.tol = sizeof(T) == 4 ? 1e-6 : 1e-9;
         MMW_TRY(Xh.alloc(eng.bs));
+        const double t_2 = tnow();
         MMW_TRY(setup_blocking());
+        const double t_3 = tnow();
+        if (verbose) fprintf(stderr, "[create] pattern %.1f ms, uploads+alloc %.1f ms, blocking %.1f ms\n", (t_1 - t_0) * 1e3, (t_2 - t_1) * 1e3, (t_3 - t_2) * 1e3);
         size_t big = std::max(std::max(nnz, C), eng.bs);
         MMW_TRY(out64.alloc(big));
         MMW_TRY(stage64.alloc((size_t)K * D));
