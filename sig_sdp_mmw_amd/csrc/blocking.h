@@ -20,7 +20,7 @@ namespace mmw {
 
 constexpr int BLK_UNION = 448;      // rows of the staged tile (448 x 256 B = 112 KiB of the 160 KiB LDS)
 constexpr int BLK_ROWS = 64;        // max matrix rows per block
-constexpr int BLK_META_BYTES = 39936;  // LDS bytes for the block's (local index, value) entries
+constexpr int BLK_META_BYTES = 38144;  // LDS bytes for the block's (local index, value) entries
 constexpr int BLK_CHUNK = 16;       // entries per wave step (4 lane groups x 4); rows are padded to this
 
 struct HostBlocking {

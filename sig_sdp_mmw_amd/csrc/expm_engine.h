@@ -59,7 +59,7 @@ inline int spmm_blk_launch(hipStream_t st, const BlkDev& B, int Dpad, const T* v
     tpw = tpw < 1 ? 1 : (tpw > ntiles ? ntiles : tpw);
     const int total = B.nb * ((ntiles + tpw - 1) / tpw);
     const int per = (total + 7) / 8;
-    const size_t sh = (size_t)BLK_UNION_ROWS * BLK_TILE_BYTES + BLK_META_LDS + BLK_ROWINFO_LDS + (size_t)BLK_WAVES * CT * sizeof(double);
+    const size_t sh = (size_t)BLK_UNION_ROWS * BLK_TILE_BYTES + BLK_META_LDS + BLK_ROWINFO_LDS + BLK_UNOFF_LDS + (size_t)BLK_WAVES * CT * sizeof(double);
     static bool attr_set = false;  // per (T, MODE) instantiation
     if (!attr_set) {
         MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_blk<T, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));

@@ -189,7 +189,8 @@ constexpr int BLK_THREADS = 1024;
 constexpr int BLK_WAVES = BLK_THREADS / WAVE;
 constexpr int BLK_TILE_BYTES = 256;
 constexpr int BLK_UNION_ROWS = 448;
-constexpr int BLK_META_LDS = 39936;   // staged (offset, value) entries
+constexpr int BLK_META_LDS = 38144;   // staged (offset, value) entries
+constexpr int BLK_UNOFF_LDS = BLK_UNION_ROWS * 4;  // element offsets of the union rows (kept out of the register file)
 constexpr int BLK_ROWINFO_LDS = 1024;  // 64 rows x {first entry, chunks, output row, own staged row}
 template <typename T> struct BlkMeta {  // one staged entry
     unsigned int li;
@@ -231,7 +232,8 @@ __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, in
     T* tile = reinterpret_cast<T*>(smem_raw);                                                        // [BLK_UNION_ROWS][CT]
     BlkMeta<T>* meta = reinterpret_cast<BlkMeta<T>*>(smem_raw + (size_t)BLK_UNION_ROWS * BLK_TILE_BYTES);  // [entries]
     int4* rowinfo = reinterpret_cast<int4*>(smem_raw + (size_t)BLK_UNION_ROWS * BLK_TILE_BYTES + BLK_META_LDS);  // [64]
-    double* shdot = reinterpret_cast<double*>(smem_raw + (size_t)BLK_UNION_ROWS * BLK_TILE_BYTES + BLK_META_LDS + BLK_ROWINFO_LDS);  // [BLK_WAVES][CT]
+    unsigned* unoff = reinterpret_cast<unsigned*>(smem_raw + (size_t)BLK_UNION_ROWS * BLK_TILE_BYTES + BLK_META_LDS + BLK_ROWINFO_LDS);  // [BLK_UNION_ROWS]
+    double* shdot = reinterpret_cast<double*>(smem_raw + (size_t)BLK_UNION_ROWS * BLK_TILE_BYTES + BLK_META_LDS + BLK_ROWINFO_LDS + BLK_UNOFF_LDS);  // [BLK_WAVES][CT]
     // XCD-aware id: consecutive ids of one XCD walk consecutive row blocks of one tile group
     const int ngroups = (ntiles + tpw - 1) / tpw;
     const int total = B.nb * ngroups;
@@ -250,17 +252,26 @@ __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, in
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int g = lane >> 4;  // lane group = one nonzero per LDS read
     // this thread's share of the union (same rows for every tile)
-    unsigned gbase[NG];  // element offsets of the union rows (K * Dpad < 2^32)
+    unsigned gbase[NG];  // element offsets of the union rows (K * Dpad < 2^32); live only until they are parked in LDS
 #pragma unroll
     for (int j = 0; j < NG; ++j) gbase[j] = (unsigned)B.un_fixed[(size_t)rb * BLK_UNION_ROWS + u0 + j * RPP] * (unsigned)Dpad;
     T x[NG][VEC];
-    auto gather = [&](int t) {
+    auto gather0 = [&](int t) {  // first tile: offsets still in registers
         const int c = t * CT + l16 * VEC;
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
 #pragma unroll
             for (int v = 0; v < VEC; ++v) x[j][v] = T(0);
             if (u0 + j * RPP < nun && c < Dpad) load16(U + (size_t)gbase[j] + c, x[j]);
+        }
+    };
+    auto gather = [&](int t) {  // later tiles: offsets come back from LDS
+        const int c = t * CT + l16 * VEC;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) x[j][v] = T(0);
+            if (u0 + j * RPP < nun && c < Dpad) load16(U + (size_t)unoff[u0 + j * RPP] + c, x[j]);
         }
     };
     auto deposit = [&]() {
@@ -289,7 +300,10 @@ __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, in
         const int b0 = B.bptr[q];
         ri = make_int4(b0 - m0, (B.bptr[q + 1] - b0) >> 4, B.order[q], (int)B.self_li[q] * BLK_TILE_BYTES);
     }
-    gather(t0);
+    gather0(t0);
+    if (l16 == 0)
+#pragma unroll
+        for (int j = 0; j < NG; ++j) unoff[u0 + j * RPP] = gbase[j];
     if ((int)threadIdx.x < q1 - q0) rowinfo[threadIdx.x] = ri;
 #pragma unroll
     for (int k = 0; k < NM; ++k) {
@@ -310,17 +324,23 @@ __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, in
         if (t + 1 < t1) gather(t + 1);  // next tile's rows fly while this tile is consumed from LDS
         const int col0 = t * CT;
         const bool colok = col0 + l16 * VEC < Dpad;
-        T dot[VEC];  // alpha numerators of this wave's (few) rows for this tile; widened when they leave the wave
+        if (MODE == SPMM_LANCZOS && g == 0) {  // alpha numerators of this wave's rows accumulate in its own LDS row
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) dot[v] = T(0);
+            for (int v = 0; v < VEC; ++v) shdot[wib * CT + l16 * VEC + v] = 0.0;
+        }
         for (int q = q0 + wib; q < q1; q += BLK_WAVES) {
             T acc[VEC];
 #pragma unroll
             for (int v = 0; v < VEC; ++v) acc[v] = T(0);
             // wave-uniform row extent -> scalar loop control, no divergence in the hot loop
-            const int4 rinfo = rowinfo[q - q0];
-            const int beg = __builtin_amdgcn_readfirstlane(rinfo.x);
-            const int nch = __builtin_amdgcn_readfirstlane(rinfo.y);
+            int beg, nch, out_row, self_off;  // wave-uniform: scalar registers, scalar loop control
+            {
+                const int4 rinfo = rowinfo[q - q0];
+                beg = __builtin_amdgcn_readfirstlane(rinfo.x);
+                nch = __builtin_amdgcn_readfirstlane(rinfo.y);
+                out_row = __builtin_amdgcn_readfirstlane(rinfo.z);
+                self_off = __builtin_amdgcn_readfirstlane(rinfo.w);
+            }
             const BlkMeta<T>* mp = meta + beg + 4 * g;
             const char* tbase = reinterpret_cast<const char*>(tile) + l16 * 16;
             // two register sets (A/B) alternate: the entries of chunk k+1 are requested BEFORE the staged rows of
@@ -361,7 +381,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, in
                 acc[v] += __shfl_xor(acc[v], 32, WAVE);
             }
             if (g == 0 && colok) {
-                const int row = rinfo.z;
+                const int row = out_row;
                 const size_t off = (size_t)row * Dpad + col0 + l16 * VEC;
                 T o[VEC];
                 if (MODE == SPMM_PLAIN) {
@@ -369,11 +389,11 @@ __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, in
                     for (int v = 0; v < VEC; ++v) o[v] = (T)(ascale * (double)acc[v]);
                 } else if (MODE == SPMM_LANCZOS) {
                     T u[VEC];
-                    load16(reinterpret_cast<const T*>(tbase + rinfo.w), u);  // U[row] is in the staged union (diagonal entry)
+                    load16(reinterpret_cast<const T*>(tbase + self_off), u);  // U[row] is in the staged union (diagonal entry)
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
                         o[v] = (T)(ascale * (double)acc[v]);
-                        dot[v] += u[v] * o[v];
+                        shdot[wib * CT + l16 * VEC + v] += (double)u[v] * (double)o[v];
                     }
                 } else if (MODE == SPMM_AXPBY) {
                     T f[VEC], x2[VEC];
@@ -383,7 +403,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, in
                     for (int v = 0; v < VEC; ++v) o[v] = (T)(ascale * (double)acc[v] + shift * (double)f[v] + inv_k * (double)x2[v]);
                 } else {
                     T u[VEC], f[VEC];
-                    load16(reinterpret_cast<const T*>(tbase + rinfo.w), u);
+                    load16(reinterpret_cast<const T*>(tbase + self_off), u);
                     load16(F + off, f);
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
@@ -394,11 +414,6 @@ __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, in
                 }
                 store16(Out + off, o);
             }
-        }
-        if (MODE == SPMM_LANCZOS) {
-            if (g == 0)
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) shdot[wib * CT + l16 * VEC + v] = (double)dot[v];
         }
         if (t == t0) MMW_STAMP(5);
         __syncthreads();  // every wave is done with this tile (and shdot is complete)
