@@ -162,7 +162,9 @@ def main():
                     traffic = rec["traffic_bytes_per_launch"]
             except Exception:
                 pass
-    roofline = {"bound": "hbm", "kernel": "k_spmm (CSR SpMM of the Lanczos/Taylor step)", "achieved": round(achieved, 1),
+    blocked = bool(solver.read(_lib.F_BLOCKING)[0])
+    kname = ("k_spmm_blk (LDS-staged locality-blocked CSR SpMM" if blocked else "k_spmm (generic CSR gather SpMM") + " of the %s step)" % args.expm
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "bytes_per_launch": int(b_spmm), "avg_launch_us": round(spmm_avg_us, 2), "launches": int(spmm_n),
                 "launches_per_step": round(spmm_n / max(args.steps, 1), 2)}
