@@ -233,32 +233,77 @@ __global__ __launch_bounds__(BLOCK) void k_sddmm(PatternDev<T> P, int Dpad, int 
             xval[dp] = xd;
             if (accumulate) xavg[dp] += xd;
         }
-        // entries right of the diagonal are the upper-triangular edges of this row
-        for (int e0 = dp + 1; e0 < end; e0 += G) {
-            const int e = e0 + g;
-            double s = 0.0;
-            if (active && e < end) {
-                const int b = P.col[e];
+        // entries right of the diagonal are the upper-triangular edges of this row; UNR edges per lane group are in
+        // flight at once (the loop is latency-bound on the gathers otherwise)
+        constexpr int UNR = 4;
+        for (int e0 = dp + 1; e0 < end; e0 += G * UNR) {
+            int ee[UNR];
+            double s[UNR];
+            T yb[UNR][NCH][VEC];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                ee[u] = e0 + g + u * G;
+                s[u] = 0.0;
+                const bool ok = active && ee[u] < end;
+                const int b = ok ? P.col[ee[u]] : row;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) yb[u][c][v] = T(0);
+                    if (ok && lig + 64 * c < LPR) load16(Yb + (size_t)b * Dpad + (size_t)(lig + 64 * c) * VEC, yb[u][c]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
 #pragma unroll
                 for (int c = 0; c < NCH; ++c)
-                    if (lig + 64 * c < LPR) {
-                        T yb[VEC];
-                        load16(Yb + (size_t)b * Dpad + (size_t)(lig + 64 * c) * VEC, yb);
 #pragma unroll
-                        for (int v = 0; v < VEC; ++v) s += (double)ya[c][v] * (double)yb[v];
+                    for (int v = 0; v < VEC; ++v) s[u] += (double)ya[c][v] * (double)yb[u][c][v];
+            if (NCH == 1 && LPR >= 4) {
+                // transposed reduction of the 4 partial sums over the LPR lanes of a group: two halving steps leave
+                // one edge per lane quarter (5 shuffles instead of 16), then the quarter is summed; the lane quarter
+                // (lig / (LPR/4)) of edge u ends up holding its total, so one store serves 4 edges per group
+                const int h = LPR >> 1, q4 = LPR >> 2;
+                const bool up = (lig & h) != 0;
+                T a0 = (T)(up ? s[2] : s[0]), a1 = (T)(up ? s[3] : s[1]);        // kept pair
+                const T b0 = (T)(up ? s[0] : s[2]), b1 = (T)(up ? s[1] : s[3]);  // sent pair
+                a0 += __shfl_xor(b0, h, WAVE);
+                a1 += __shfl_xor(b1, h, WAVE);
+                const bool up2 = (lig & q4) != 0;
+                T r = up2 ? a1 : a0;
+                const T snd = up2 ? a0 : a1;
+                r += __shfl_xor(snd, q4, WAVE);
+                for (int o = q4 >> 1; o > 0; o >>= 1) r += __shfl_xor(r, o, WAVE);
+                const int u = (up ? 2 : 0) + (up2 ? 1 : 0);  // the edge this lane quarter holds
+                const int e = e0 + g + u * G;
+                if (active && e < end && (lig & (q4 - 1)) == 0) {
+                    const T x = (T)((double)r / tr);
+                    const int me = P.mirror[e];
+                    xval[e] = x;
+                    xval[me] = x;
+                    if (accumulate) {
+                        xavg[e] += x;
+                        xavg[me] += x;
                     }
-            }
-            if (NCH == 1) s = group_sum(s, LPR);  // LPR is a power of two (or 64) when NCH == 1
-            else s = wave_sum(s);
-            if (active && e < end && lig == 0) {
-                const T x = (T)(s / tr);
-                const int me = P.mirror[e];
-                xval[e] = x;
-                xval[me] = x;
-                if (accumulate) {
-                    xavg[e] += x;
-                    xavg[me] += x;
                 }
+            } else {
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    if (NCH == 1 && G > 1) s[u] = group_sum(s[u], LPR);  // LPR is a power of two when several groups share a wave
+                    else s[u] = wave_sum(s[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+                    if (active && ee[u] < end && lig == 0) {
+                        const T x = (T)(s[u] / tr);
+                        const int me = P.mirror[ee[u]];
+                        xval[ee[u]] = x;
+                        xval[me] = x;
+                        if (accumulate) {
+                            xavg[ee[u]] += x;
+                            xavg[me] += x;
+                        }
+                    }
             }
         }
     }
