@@ -13,18 +13,20 @@
 #include <cstdint>
 #include <cstdlib>
 #include <numeric>
+#include "blk_config.h"
 #include <queue>
 #include <vector>
 
 namespace mmw {
 
-constexpr int BLK_UNION = 448;      // rows of the staged tile (448 x 256 B = 112 KiB of the 160 KiB LDS)
+constexpr int BLK_UNION = MMW_BLK_UNION;      // rows of the staged tile (448 x 256 B = 112 KiB of the 160 KiB LDS)
 constexpr int BLK_ROWS = 64;        // max matrix rows per block
-constexpr int BLK_META_BYTES = 38144;  // LDS bytes for the block's (local index, value) entries
+constexpr int BLK_META_BYTES = MMW_BLK_META;  // LDS bytes for the block's (local index, value) entries
 constexpr int BLK_CHUNK = 16;       // entries per wave step (4 lane groups x 4); rows are padded to this
 
 struct HostBlocking {
     bool usable = false;
+    bool fits_half_tile = false;        // every block also fits the half-tile kernel's LDS budget
     double reuse = 0.0;                 // nnz / sum of union sizes
     std::vector<int32_t> order;         // RCM order: position -> original row
     std::vector<int32_t> blk_rowptr;    // [nb+1] into `order`
@@ -100,13 +102,29 @@ inline std::vector<int32_t> rcm_order(int K, const std::vector<int32_t>& indptr,
     return order;
 }
 
+// LDS budget of the half-tile kernel (k_spmm_blk2: two workgroups per CU): a fixed header, the union's rows at
+// 128 B each, then the block's staged entries
+constexpr int BLK2_LDS_BYTES = 79872;
+constexpr int BLK2_HEADER_BYTES = 4864;
+constexpr int BLK2_ROW_BYTES = 128;
+struct BlockingLimits {
+    int max_entries_per_block;  // staged entries of the full-tile kernel
+    int entry_bytes;            // sizeof one staged entry (offset + value)
+};
+inline int blk2_lds_need(int nun, int64_t entries, int entry_bytes) {
+    return BLK2_HEADER_BYTES + ((nun + 7) & ~7) * BLK2_ROW_BYTES + ((int)entries + 2 * 16) * entry_bytes;  // two chunks of slack: the pair prefetch reads ahead
+}
+
 inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& indptr, const std::vector<int32_t>& indices,
-                           int max_entries_per_block) {
+                           const BlockingLimits& lim) {
+    const int max_entries_per_block = lim.max_entries_per_block;
     const int64_t nnz = indptr[K];
     B.usable = false;
     auto padded = [](int n) { return (n + BLK_CHUNK - 1) / BLK_CHUNK * BLK_CHUNK; };
     for (int k = 0; k < K; ++k)
-        if (padded(indptr[k + 1] - indptr[k]) > max_entries_per_block) return;
+        if (padded(indptr[k + 1] - indptr[k]) + BLK_CHUNK > max_entries_per_block ||
+            blk2_lds_need(indptr[k + 1] - indptr[k], padded(indptr[k + 1] - indptr[k]) + BLK_CHUNK, lim.entry_bytes) > BLK2_LDS_BYTES)
+            return;
     for (int k = 0; k < K; ++k)
         if (indptr[k + 1] - indptr[k] > BLK_UNION) return;  // a single row overflows the tile: generic kernel
     B.order = rcm_order(K, indptr, indices);
@@ -116,7 +134,7 @@ inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& i
     B.blk_rowptr.assign(1, 0);
     B.un_ptr.assign(1, 0);
     B.un_cols.clear();
-    std::vector<int32_t> stamp(K, -1), cur;
+    std::vector<int32_t> stamp(K, -1), loc(K, 0), cur;
     int blk = 0, p = 0;
     const int row_cap = getenv("MMW_BLK_ROWS") ? atoi(getenv("MMW_BLK_ROWS")) : BLK_ROWS;
     const int row_quant = getenv("MMW_BLK_QUANT") ? atoi(getenv("MMW_BLK_QUANT")) : 1;
@@ -129,8 +147,10 @@ inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& i
             int fresh = 0;
             for (int e = indptr[r]; e < indptr[r + 1]; ++e)
                 if (stamp[indices[e]] != blk) ++fresh;
-            const int pe = padded(indptr[r + 1] - indptr[r]);
-            if (rows > 0 && ((int)cur.size() + fresh > BLK_UNION || entries + pe > max_entries_per_block)) break;
+            const int pe = padded(indptr[r + 1] - indptr[r]) + BLK_CHUNK;  // room for the parity padding (exact count below)
+            if (rows > 0 && ((int)cur.size() + fresh > BLK_UNION || entries + pe > max_entries_per_block ||
+                             blk2_lds_need((int)cur.size() + fresh, entries + pe, lim.entry_bytes) > BLK2_LDS_BYTES))
+                break;
             entries += pe;
             for (int e = indptr[r]; e < indptr[r + 1]; ++e)
                 if (stamp[indices[e]] != blk) {
@@ -155,6 +175,30 @@ inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& i
             }
         }
         std::sort(cur.begin(), cur.end(), [&](int a, int b) { return rank[a] < rank[b]; });
+        // exact staged entry count under the parity arrangement; shed rows until both kernels' budgets hold
+        for (;;) {
+            for (size_t u = 0; u < cur.size(); ++u) loc[cur[u]] = (int32_t)u;
+            int64_t exact = 0;
+            for (int q = p_start; q < p; ++q) {
+                const int r = B.order[q];
+                int ne = 0, no = 0;
+                for (int e = indptr[r]; e < indptr[r + 1]; ++e) ((loc[indices[e]] & 1) ? no : ne)++;
+                exact += (int64_t)BLK_CHUNK * std::max(1, std::max((ne + 7) / 8, (no + 7) / 8));
+            }
+            if (p - p_start <= 1 || (exact <= max_entries_per_block && blk2_lds_need((int)cur.size(), exact, lim.entry_bytes) <= BLK2_LDS_BYTES)) break;
+            --p;
+            cur.clear();
+            ++blk;
+            for (int q = p_start; q < p; ++q) {
+                const int r = B.order[q];
+                for (int e = indptr[r]; e < indptr[r + 1]; ++e)
+                    if (stamp[indices[e]] != blk) {
+                        stamp[indices[e]] = blk;
+                        cur.push_back(indices[e]);
+                    }
+            }
+            std::sort(cur.begin(), cur.end(), [&](int a, int b) { return rank[a] < rank[b]; });
+        }
         B.un_cols.insert(B.un_cols.end(), cur.begin(), cur.end());
         B.un_ptr.push_back((int32_t)B.un_cols.size());
         B.blk_rowptr.push_back(p);
@@ -168,12 +212,12 @@ inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& i
     B.sd_max = 0;
     B.lidx.clear();
     B.bepos.clear();
-    B.lidx.reserve(nnz + (int64_t)K * BLK_CHUNK);
-    B.bepos.reserve(nnz + (int64_t)K * BLK_CHUNK);
+    B.lidx.reserve(nnz + (int64_t)K * 2 * BLK_CHUNK);
+    B.bepos.reserve(nnz + (int64_t)K * 2 * BLK_CHUNK);
     B.bpos.resize(nnz);
     std::vector<int32_t> local(K, -1);
     int64_t w = 0;
-    std::vector<std::pair<uint16_t, int32_t>> rowbuf;
+    std::vector<std::pair<uint16_t, int32_t>> rowbuf, oddbuf;
     for (int b = 0; b < B.nb(); ++b) {
         if (b > 0)
             for (int u = B.un_ptr[b - 1]; u < B.un_ptr[b]; ++u) local[B.un_cols[u]] = -1;
@@ -181,20 +225,34 @@ inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& i
         for (int q = B.blk_rowptr[b]; q < B.blk_rowptr[b + 1]; ++q) {
             const int r = B.order[q];
             B.self_li[q] = local[r] >= 0 ? (uint16_t)local[r] : (uint16_t)0;
+            // Entries in chunks of 16, eight staged rows of even local index and eight of odd: the half-tile kernel
+            // reads 128-byte staged rows with 8-lane groups, and the lane groups that share an LDS service group
+            // (0|3, 1|2, 4|7, 5|6) then always land on different bank halves.  Chunk positions with bit 2 clear
+            // hold even rows, the others odd rows; holes are (row 0 or 1, value 0) entries.
             rowbuf.clear();
-            for (int e = indptr[r]; e < indptr[r + 1]; ++e) rowbuf.emplace_back((uint16_t)local[indices[e]], e);
+            oddbuf.clear();
+            for (int e = indptr[r]; e < indptr[r + 1]; ++e) {
+                const uint16_t li = (uint16_t)local[indices[e]];
+                ((li & 1) ? oddbuf : rowbuf).emplace_back(li, e);
+            }
             std::sort(rowbuf.begin(), rowbuf.end());
-            for (auto& pr : rowbuf) {
-                B.lidx.push_back(pr.first);
-                B.bepos.push_back(pr.second);
-                B.bpos[pr.second] = (int32_t)w;
-                ++w;
-            }
-            while (w % BLK_CHUNK) {  // pad the row: (index 0, value 0) entries contribute nothing
-                B.lidx.push_back(0);
-                B.bepos.push_back(-1);
-                ++w;
-            }
+            std::sort(oddbuf.begin(), oddbuf.end());
+            const int nch = std::max(1, (int)std::max((rowbuf.size() + 7) / 8, (oddbuf.size() + 7) / 8));
+            for (int c = 0; c < nch; ++c)
+                for (int p = 0; p < BLK_CHUNK; ++p) {
+                    const bool odd = (p & 4) != 0;
+                    const size_t i = (size_t)c * 8 + (p & 3) + ((p & 8) ? 4 : 0);
+                    const auto& src = odd ? oddbuf : rowbuf;
+                    if (i < src.size()) {
+                        B.lidx.push_back(src[i].first);
+                        B.bepos.push_back(src[i].second);
+                        B.bpos[src[i].second] = (int32_t)w;
+                    } else {
+                        B.lidx.push_back(odd ? 1 : 0);
+                        B.bepos.push_back(-1);
+                    }
+                    ++w;
+                }
             B.bptr[q + 1] = (int32_t)w;
             for (int e = indptr[r]; e < indptr[r + 1]; ++e)
                 if (indices[e] > r) {
@@ -218,7 +276,14 @@ inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& i
         for (int u = 0; u < BLK_UNION; ++u) B.un_fixed[(size_t)b * BLK_UNION + u] = B.un_cols[B.un_ptr[b] + (u < nun ? u : 0)];
     }
     B.reuse = B.un_cols.empty() ? 0.0 : (double)nnz / (double)B.un_cols.size();
-    B.usable = B.reuse >= 2.0;
+    B.fits_half_tile = true;
+    bool fits_full = true;
+    for (int b = 0; b < B.nb(); ++b) {
+        const int32_t* d = &B.desc[(size_t)b * 8];
+        if (d[3] > max_entries_per_block) fits_full = false;
+        if (blk2_lds_need(d[5], d[3], lim.entry_bytes) > BLK2_LDS_BYTES) B.fits_half_tile = false;
+    }
+    B.usable = B.reuse >= 2.0 && fits_full;
 }
 
 }  // namespace mmw

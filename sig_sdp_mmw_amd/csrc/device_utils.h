@@ -40,19 +40,99 @@ __device__ __forceinline__ void store16(double* p, const double (&x)[2]) {
     *reinterpret_cast<double2*>(p) = make_double2(x[0], x[1]);
 }
 
-// butterfly all-reduce over `width` consecutive lanes (width a power of two <= 64)
-template <typename R> __device__ __forceinline__ R group_sum(R v, int width) {
-    for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
+// ---- cross-lane exchanges without LDS traffic ---------------------------------------------------
+// __shfl_xor compiles to ds_bpermute_b32, which occupies the LDS pipe the blocked kernels are bound by.
+// Within a 16-lane row DPP modifiers do the exchange in the VALU; across rows gfx950 has v_permlane16_swap /
+// v_permlane32_swap, which with both operands equal leave (even rows' value, odd rows' value) in the two results.
+template <int CTRL> __device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
 }
-template <typename R> __device__ __forceinline__ R wave_sum(R v) { return group_sum(v, WAVE); }
-template <typename R> __device__ __forceinline__ R wave_max(R v) {
-    for (int o = WAVE >> 1; o > 0; o >>= 1) {
-        const R w = __shfl_xor(v, o, WAVE);
-        v = w > v ? w : v;
+template <int CTRL> __device__ __forceinline__ float dpp(float v) { return __uint_as_float(dpp_u32<CTRL>(__float_as_uint(v))); }
+template <int CTRL> __device__ __forceinline__ int dpp(int v) { return (int)dpp_u32<CTRL>((unsigned)v); }
+template <int CTRL> __device__ __forceinline__ double dpp(double v) {
+    const unsigned long long w = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = dpp_u32<CTRL>((unsigned)w), hi = dpp_u32<CTRL>((unsigned)(w >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1;      // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;      // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_ROR1 = 0x121, DPP_ROW_ROR2 = 0x122, DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128;
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;
+// (a, b) = (value held by the even 16-lane rows, by the odd rows) of each row pair, in every lane of the pair
+__device__ __forceinline__ void rows16(float v, float& a, float& b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void rows32(float v, float& a, float& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void rows16(int v, int& a, int& b) {
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    a = (int)r[0]; b = (int)r[1];
+}
+__device__ __forceinline__ void rows32(int v, int& a, int& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    a = (int)r[0]; b = (int)r[1];
+}
+__device__ __forceinline__ void rows16(double v, double& a, double& b) {
+    const unsigned long long w = (unsigned long long)__double_as_longlong(v);
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)w, (unsigned)w, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(w >> 32), (unsigned)(w >> 32), false, false);
+    a = __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0]));
+    b = __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));
+}
+__device__ __forceinline__ void rows32(double v, double& a, double& b) {
+    const unsigned long long w = (unsigned long long)__double_as_longlong(v);
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)w, (unsigned)w, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(w >> 32), (unsigned)(w >> 32), false, false);
+    a = __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0]));
+    b = __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));
+}
+// value held by lane (l ^ o), o a wave-uniform power of two
+template <typename R> __device__ __forceinline__ R lane_xor(R v, int o) {
+    const int lane = threadIdx.x & 63;
+    switch (o) {
+        case 32: { R a, b; rows32(v, a, b); return lane & 32 ? a : b; }
+        case 16: { R a, b; rows16(v, a, b); return lane & 16 ? a : b; }
+        case 8: return dpp<DPP_ROW_ROR8>(v);
+        case 4: { const R up = dpp<0x104>(v), dn = dpp<0x114>(v); return lane & 4 ? dn : up; }  // row_shl:4 / row_shr:4
+        case 2: return dpp<DPP_QUAD_XOR2>(v);
+        default: return dpp<DPP_QUAD_XOR1>(v);
     }
+}
+// sum over the lanes l' == l (mod stride), stride a wave-uniform power of two: every lane gets its class total
+template <typename R> __device__ __forceinline__ R stride_sum(R v, int stride) {
+    if (stride <= 32) { R a, b; rows32(v, a, b); v = a + b; }
+    if (stride <= 16) { R a, b; rows16(v, a, b); v = a + b; }
+    if (stride <= 8) v += dpp<DPP_ROW_ROR8>(v);   // from here the values repeat every 8 / 4 / 2 lanes, so a
+    if (stride <= 4) v += dpp<DPP_ROW_ROR4>(v);   // rotation fetches the same value the xor partner holds
+    if (stride <= 2) v += dpp<DPP_ROW_ROR2>(v);
+    if (stride <= 1) v += dpp<DPP_ROW_ROR1>(v);
     return v;
 }
+struct OpSum { template <typename R> __device__ __forceinline__ R operator()(R a, R b) const { return a + b; } };
+struct OpMax { template <typename R> __device__ __forceinline__ R operator()(R a, R b) const { return b > a ? b : a; } };
+// all-reduce over aligned groups of `width` consecutive lanes (a power of two <= 64); every lane gets the result,
+// and every lane of a group combines the operands in the same order
+template <typename R, typename Op> __device__ __forceinline__ R group_reduce(R v, int width, Op op) {
+    if (width >= 64) { R a, b; rows32(v, a, b); v = op(a, b); }
+    if (width >= 32) { R a, b; rows16(v, a, b); v = op(a, b); }
+    if (width >= 16) {
+        v = op(v, dpp<DPP_ROW_ROR8>(v));
+        v = op(v, dpp<DPP_ROW_ROR4>(v));
+        v = op(v, dpp<DPP_ROW_ROR2>(v));
+        v = op(v, dpp<DPP_ROW_ROR1>(v));
+        return v;
+    }
+    if (width >= 8) v = op(v, dpp<DPP_ROW_HALF_MIRROR>(v));
+    if (width >= 4) v = op(v, dpp<DPP_QUAD_XOR2>(v));
+    if (width >= 2) v = op(v, dpp<DPP_QUAD_XOR1>(v));
+    return v;
+}
+template <typename R> __device__ __forceinline__ R group_sum(R v, int width) { return group_reduce(v, width, OpSum()); }
+template <typename R> __device__ __forceinline__ R wave_sum(R v) { return group_reduce(v, WAVE, OpSum()); }
+template <typename R> __device__ __forceinline__ R wave_max(R v) { return group_reduce(v, WAVE, OpMax()); }
 
 // workgroup reductions through LDS; every thread gets the result. `sh` needs WAVES_PER_BLOCK entries.
 template <typename R> __device__ __forceinline__ R block_sum(R v, R* sh) {

@@ -52,6 +52,24 @@ inline unsigned long long* g_blk_stamps = nullptr;  // diagnostic builds only: p
 template <typename T, int MODE>
 inline int spmm_blk_launch(hipStream_t st, const BlkDev& B, int Dpad, const T* val_blk, const T* in, T* out, T* F, const T* X2,
                            double c1, double c2, double c3, double* partial, const ExpmPlan* plan = nullptr, int step = 0) {
+    if (B.half_tile) {
+        constexpr int CT2 = B2_ROW_BYTES / (int)sizeof(T);
+        const int ntiles = (Dpad + CT2 - 1) / CT2;
+        int tpw = (int)((double)B.nb * ntiles / (4.0 * 512.0) + 0.5);  // ~4 rounds of the 512 resident workgroups
+        if (getenv("MMW_TPW")) tpw = atoi(getenv("MMW_TPW"));
+        tpw = tpw < 1 ? 1 : (tpw > ntiles ? ntiles : tpw);
+        const int total = B.nb * ((ntiles + tpw - 1) / tpw);
+        const int per = (total + 7) / 8;
+        static bool attr2_set = false;  // per (T, MODE) instantiation
+        if (!attr2_set) {
+            MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_blk2<T, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS_BYTES));
+            attr2_set = true;
+        }
+        static const int late = getenv("MMW_LATE_GATHER") ? 0x100 : 0;
+        hipLaunchKernelGGL((k_spmm_blk2<T, MODE>), dim3(per * 8), dim3(B2_THREADS), B2_LDS_BYTES, st, B, Dpad, ntiles, tpw | late, val_blk, in, out, F, X2, c1, c2, c3, partial, plan, step, g_blk_stamps);
+        MMW_HIP(hipGetLastError());
+        return MMW_OK;
+    }
     constexpr int CT = BLK_TILE_BYTES / (int)sizeof(T);
     const int ntiles = (Dpad + CT - 1) / CT;
     int tpw = (int)((double)B.nb * ntiles / (3.0 * 256.0) + 0.5);  // ~3 workgroups per CU over the launch
@@ -82,7 +100,7 @@ template <typename T> struct ExpmEngine {
     const T* val = nullptr;
     DevBuf<T> U;        // (max_order + 1) blocks of K*Dpad; block 0 is the start block
     DevBuf<T> Tm;       // A * U_j
-    DevBuf<double> partial, colsum, scal, rho_part, trace_own;
+    DevBuf<double> partial, partial_sq, colsum, scal, rho_part, trace_own;  // partial: alpha numerators; partial_sq: column sums of squares
     DevBuf<ExpmPlan> plan_d;
     DevBuf<int> viol_d;
     ExpmPlan* plan_h = nullptr;  // pinned
@@ -121,6 +139,7 @@ template <typename T> struct ExpmEngine {
         MMW_TRY(ensure_blocks(4));  // the basis grows on demand: the MMW loop rarely needs more than 3 vectors
         MMW_TRY(Tm.alloc(bs));
         MMW_TRY(partial.alloc((size_t)MAX_PART * lay.Dpad));
+        MMW_TRY(partial_sq.alloc((size_t)MAX_PART * lay.Dpad));
         npart = nblk;
         MMW_TRY(colsum.alloc(lay.Dpad));
         MMW_TRY(scal.alloc((size_t)4 * (MAX_ORDER + 2) * lay.Dpad));
@@ -240,28 +259,29 @@ template <typename T> struct ExpmEngine {
             if (method == MMW_EXPM_LANCZOS) {
                 LanczosScalars S = scalars();
                 const int gr = grid_rows(K * 4);  // k_colsq / k_lz_update stride rows by workgroup
-                MMW_TRY(kbegin(KT_KRYLOV_VEC));
-                if (sub == 0 && start_colsq_ready) {
-                    MMW_TRY((colreduce<LZ_INIT>(npart_start, 0, pd)));
-                } else {
-                    hipLaunchKernelGGL((k_colsq<T>), dim3(gr), dim3(BLOCK), shcol, st, K, Dpad, U.p, partial.p);
-                    MMW_TRY((colreduce<LZ_INIT>(gr, 0, pd)));
+                const double eps = sizeof(T) == 4 ? 1e-6 : 1e-14;
+                int nsq = npart_start;  // slabs of column sums of squares waiting in partial_sq
+                if (!(sub == 0 && start_colsq_ready)) {
+                    MMW_TRY(kbegin(KT_KRYLOV_VEC));
+                    hipLaunchKernelGGL((k_colsq<T>), dim3(gr), dim3(BLOCK), shcol, st, K, Dpad, U.p, partial_sq.p);
+                    MMW_TRY(kend());
+                    nsq = gr;
                 }
                 start_colsq_ready = false;
-                MMW_TRY(kend());
                 for (int j = 1; j <= m; ++j) {
                     MMW_TRY((launch_spmm<SPMM_LANCZOS>(block(j - 1), Tm.p, nullptr, ascale, 0.0, 1.0, pd, j)));
                     MMW_TRY(kbegin(KT_KRYLOV_VEC));
-                    MMW_TRY((colreduce<LZ_ALPHA>(npart, j, pd)));
+                    // one launch: the norms of U_j, alpha_j, and after the last product the small exponentials
+                    hipLaunchKernelGGL(k_lz_scalars, dim3((Dpad + 15) / 16), dim3(1024), 0, st, npart, partial.p, nsq, partial_sq.p, Dpad, j, m,
+                                       1.0 / nsub, eps, S, pd);
                     if (j < m) {  // the last product A U_m goes straight into the combination (corrected scheme)
                         hipLaunchKernelGGL((k_lz_update<T>), dim3(gr), dim3(BLOCK), shcol, st, K, Dpad, j, Tm.p, block(j - 1),
-                                           j > 1 ? block(j - 2) : block(j - 1), block(j), S, partial.p, pd);
-                        MMW_TRY((colreduce<LZ_BETA>(gr, j, pd)));
+                                           j > 1 ? block(j - 2) : block(j - 1), block(j), S, partial_sq.p, pd);
+                        nsq = gr;
                     }
                     MMW_TRY(kend());
                 }
                 MMW_TRY(kbegin(KT_KRYLOV_VEC));
-                hipLaunchKernelGGL(k_lz_texp, dim3(gcol), dim3(64), 0, st, Dpad, m, 1.0 / nsub, S, pd);
                 const bool last = sub + 1 == nsub;
                 hipLaunchKernelGGL((k_lz_combine<T>), dim3(nblk), dim3(BLOCK), 0, st, K, Dpad, m, U.p, bs, Tm.p, S.coef, out, pd,
                                    last ? rownorm_d : (T*)nullptr, last ? rownorm_part : (double*)nullptr);

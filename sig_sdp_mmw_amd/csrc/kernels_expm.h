@@ -9,6 +9,7 @@
 // group per nonzero: every gather is a fully coalesced LPR*16-byte row segment); for wider blocks one
 // lane covers NCH chunks 64 lanes apart.  All HBM-bound: ~0.2-2 flop/byte, so no MFMA here.
 #pragma once
+#include "blk_config.h"
 #include "device_utils.h"
 
 namespace mmw {
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmm(int K, BlockLayout lay, const in
         if (NCH == 1 && G > 1) {  // fold the G lane groups (LPR is a power of two here)
 #pragma unroll
             for (int v = 0; v < VEC; ++v)
-                for (int o = LPR; o < WAVE; o <<= 1) acc[0][v] += __shfl_xor(acc[0][v], o, WAVE);
+                acc[0][v] = stride_sum(acc[0][v], LPR);
         }
         if (g == 0) {
 #pragma unroll
@@ -184,15 +185,16 @@ struct BlkDev {
     const unsigned short* self_li;  // [K] by position: local index of the row itself (its diagonal entry)
     const int* desc;          // [nb][8] {q0, rows, m0, entries, un0, union size, chunks, 0}
     const int* un_fixed;      // [nb][BLK_UNION_ROWS] union column ids at a fixed stride
+    int half_tile;            // every block fits the half-tile kernel (k_spmm_blk2)
 };
-constexpr int BLK_THREADS = 1024;
+constexpr int BLK_THREADS = MMW_BLK_THREADS;
 constexpr int BLK_WAVES = BLK_THREADS / WAVE;
 constexpr int BLK_TILE_BYTES = 256;
-constexpr int BLK_UNION_ROWS = 448;
-constexpr int BLK_META_LDS = 38144;   // staged (offset, value) entries
+constexpr int BLK_UNION_ROWS = MMW_BLK_UNION;
+constexpr int BLK_META_LDS = MMW_BLK_META;   // staged (offset, value) entries
 constexpr int BLK_UNOFF_LDS = BLK_UNION_ROWS * 4;  // element offsets of the union rows (kept out of the register file)
 constexpr int BLK_ROWINFO_LDS = 1024;  // 64 rows x {first entry, chunks, output row, own staged row}
-template <typename T> struct BlkMeta {  // one staged entry
+template <typename T> struct alignas(2 * sizeof(T)) BlkMeta {  // one staged entry (read with one ds_read_b64 / b128)
     unsigned int li;
     T v;
 };
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, in
     auto deposit = [&]() {
 #pragma unroll
         for (int j = 0; j < NG; ++j)
-            if (u0 + j * RPP < nun) store16(tile + (size_t)(u0 + j * RPP) * CT + l16 * VEC, x[j]);
+            if (u0 + j * RPP < max(nun, 2)) store16(tile + (size_t)(u0 + j * RPP) * CT + l16 * VEC, x[j]);  // rows 0/1 back the padding entries
     };
     MMW_STAMP(1);
     // the block's entries, once for all its tiles: requested before the gathers so they land first
@@ -377,8 +379,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, in
             }
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
-                acc[v] += __shfl_xor(acc[v], 16, WAVE);
-                acc[v] += __shfl_xor(acc[v], 32, WAVE);
+                acc[v] = stride_sum(acc[v], 16);
             }
             if (g == 0 && colok) {
                 const int row = out_row;
@@ -423,6 +424,299 @@ __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, in
                 if (col0 + c < Dpad) {
                     double s = 0.0;
                     for (int w = 0; w < BLK_WAVES; ++w) s += shdot[w * CT + c];
+                    partial[(size_t)rb * Dpad + col0 + c] = s;
+                }
+        }
+        if (t + 1 < t1) {
+            deposit();
+            if (t == t0) MMW_STAMP(7);
+            __syncthreads();
+            if (t == t0) MMW_STAMP(8);
+        }
+    }
+    MMW_STAMP(9);
+#undef MMW_STAMP
+}
+
+// ---- the same product on 128-byte half tiles, two workgroups per CU ------------------------------
+// k_spmm_blk keeps one 1024-thread workgroup per CU, so every barrier, the prologue's dependent loads and the
+// gather of the next tile stall the whole CU.  Here a workgroup is 8 waves with at most 78 KiB of LDS: two are
+// resident per CU and one computes while the other waits.  A staged row is 128 B; an 8-lane group owns one
+// nonzero, so one ds_read_b128 wave-instruction serves 8 nonzeros.  The b128 service groups pair lane groups
+// 0|3, 1|2, 4|7, 5|6 on the same 16 banks of a bank half; the host orders every 16-entry chunk so that the paired
+// groups read rows of opposite parity (blocking.h), which makes every read conflict-free.
+// LDS: [rowinfo 64 x int4][1792 B spare][shdot 8 x 32 x f64][rows (nun rounded up to 8) x 128 B][entries + 2 chunks].
+constexpr int B2_THREADS = 512;
+constexpr int B2_WAVES = B2_THREADS / WAVE;
+constexpr int B2_ROW_BYTES = 128;
+constexpr int B2_LDS_BYTES = 79872;     // == BLK2_LDS_BYTES (blocking.h)
+constexpr int B2_HEADER_BYTES = 4864;   // == BLK2_HEADER_BYTES: 1024 + 1792 + 2048
+__device__ __forceinline__ void load_meta2(const BlkMeta<float>* p, unsigned (&li)[2], float (&v)[2]) {
+    const uint4 a = reinterpret_cast<const uint4*>(p)[0];
+    li[0] = a.x; v[0] = __uint_as_float(a.y); li[1] = a.z; v[1] = __uint_as_float(a.w);
+}
+__device__ __forceinline__ void load_meta2(const BlkMeta<double>* p, unsigned (&li)[2], double (&v)[2]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const uint4 a = reinterpret_cast<const uint4*>(p)[u];
+        li[u] = a.x;
+        v[u] = __longlong_as_double(((long long)a.w << 32) | (long long)a.z);
+    }
+}
+
+// acc += a * x over one 16-byte lane slice.  float: two v_pk_fma_f32 with the scalar broadcast by op_sel (the plain
+// loop is SLP-packed into pk_mul + pk_add + register shuffles, and this kernel is VALU-issue bound)
+template <typename T> struct Axpy16;
+template <> struct Axpy16<float> {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 lo = {0.f, 0.f}, hi = {0.f, 0.f};
+    __device__ __forceinline__ void add(float a, const float (&x)[4]) {
+        const f2 a2 = {a, a};
+        lo = __builtin_elementwise_fma((f2){x[0], x[1]}, a2, lo);
+        hi = __builtin_elementwise_fma((f2){x[2], x[3]}, a2, hi);
+    }
+    __device__ __forceinline__ void get(float (&o)[4]) const { o[0] = lo.x; o[1] = lo.y; o[2] = hi.x; o[3] = hi.y; }
+};
+template <> struct Axpy16<double> {
+    double s0 = 0.0, s1 = 0.0;
+    __device__ __forceinline__ void add(double a, const double (&x)[2]) {
+        s0 = __builtin_fma(a, x[0], s0);
+        s1 = __builtin_fma(a, x[1], s1);
+    }
+    __device__ __forceinline__ void get(double (&o)[2]) const { o[0] = s0; o[1] = s1; }
+};
+
+// the four entries held by the lanes of a quad, broadcast to every lane of the quad (DPP quad_perm, no LDS traffic)
+template <int Q> __device__ __forceinline__ unsigned quad_lane(unsigned w) {
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)w, Q * 0x55, 0xF, 0xF, true);
+}
+__device__ __forceinline__ void quad_bcast(const BlkMeta<float>& e, unsigned (&li)[4], float (&v)[4]) {
+    const unsigned w = __float_as_uint(e.v);
+    li[0] = quad_lane<0>(e.li); li[1] = quad_lane<1>(e.li); li[2] = quad_lane<2>(e.li); li[3] = quad_lane<3>(e.li);
+    v[0] = __uint_as_float(quad_lane<0>(w)); v[1] = __uint_as_float(quad_lane<1>(w));
+    v[2] = __uint_as_float(quad_lane<2>(w)); v[3] = __uint_as_float(quad_lane<3>(w));
+}
+__device__ __forceinline__ void quad_bcast(const BlkMeta<double>& e, unsigned (&li)[4], double (&v)[4]) {
+    const unsigned long long w = (unsigned long long)__double_as_longlong(e.v);
+    const unsigned lo = (unsigned)w, hi = (unsigned)(w >> 32);
+    li[0] = quad_lane<0>(e.li); li[1] = quad_lane<1>(e.li); li[2] = quad_lane<2>(e.li); li[3] = quad_lane<3>(e.li);
+    v[0] = __longlong_as_double((long long)(((unsigned long long)quad_lane<0>(hi) << 32) | quad_lane<0>(lo)));
+    v[1] = __longlong_as_double((long long)(((unsigned long long)quad_lane<1>(hi) << 32) | quad_lane<1>(lo)));
+    v[2] = __longlong_as_double((long long)(((unsigned long long)quad_lane<2>(hi) << 32) | quad_lane<2>(lo)));
+    v[3] = __longlong_as_double((long long)(((unsigned long long)quad_lane<3>(hi) << 32) | quad_lane<3>(lo)));
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(B2_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_spmm_blk2(BlkDev B, int Dpad, int ntiles, int tpw, const T* __restrict__ val_blk, const T* __restrict__ U, T* __restrict__ Out,
+                 T* __restrict__ F, const T* __restrict__ X2, double ascale, double shift, double inv_k, double* __restrict__ partial,
+                 const ExpmPlan* __restrict__ plan, int step, unsigned long long* __restrict__ stamps) {
+    constexpr int VEC = V16<T>::N;
+    constexpr int CT = B2_ROW_BYTES / (int)sizeof(T);  // columns per tile
+#define MMW_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    MMW_STAMP(0);
+    if (stamps && threadIdx.x == 0) {
+        stamps[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_getreg(63492);
+        stamps[(size_t)blockIdx.x * 16 + 11] = __builtin_amdgcn_s_getreg(63508);
+    }
+    if (plan) {
+        if (step > plan->m) return;
+        if (MODE == SPMM_TAYLOR) shift = plan->mu / plan->nsub;
+    }
+    const bool late_gather = (tpw & 0x100) != 0;
+    tpw &= 0xFF;
+    constexpr int RPP = B2_THREADS / 8;        // union rows gathered per pass
+    constexpr int NG = BLK_UNION_ROWS / RPP;   // gathers per thread
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    int4* rowinfo = reinterpret_cast<int4*>(smem_raw);                          // [64]
+    double* shdot = reinterpret_cast<double*>(smem_raw + 1024 + 1792);         // [B2_WAVES][CT]
+    char* tile = smem_raw + B2_HEADER_BYTES;                                   // [max(nun,2)][128 B]
+    const int ngroups = (ntiles + tpw - 1) / tpw;
+    const int total = B.nb * ngroups;
+    const int per = (total + 7) / 8;
+    const int id = (blockIdx.x & 7) * per + (blockIdx.x >> 3);  // XCD-aware: one XCD walks consecutive row blocks
+    if (id >= total) return;
+    const int tg = id / B.nb, rb = id - tg * B.nb;
+    const int t0 = tg * tpw, t1 = min(ntiles, t0 + tpw);
+    const int* dsc = B.desc + (size_t)rb * 8;
+    const int q0 = dsc[0], nrows = dsc[1];
+    const int m0 = dsc[2], nmeta = dsc[3];
+    const int nun = dsc[5];
+    BlkMeta<T>* meta = reinterpret_cast<BlkMeta<T>*>(tile + (size_t)((nun + 7) & ~7) * B2_ROW_BYTES);
+    const int l8 = threadIdx.x & 7, u0 = threadIdx.x >> 3;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int g = lane >> 3;  // lane group = one nonzero per LDS read
+    // Byte offsets of this thread's union rows, kept in registers for all tiles (K * Dpad * sizeof(T) < 4 GiB, checked by
+    // the host).  The union is staged in whole groups of 8 rows (un_fixed pads with the first column), so a wave's 8 rows
+    // are gathered or skipped together: the row test is scalar, and only the last, partial column tile tests lanes.
+    const int nun8 = (nun + 7) & ~7;
+    unsigned gbase[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j)
+        gbase[j] = (unsigned)B.un_fixed[(size_t)rb * BLK_UNION_ROWS + u0 + j * RPP] * (unsigned)(Dpad * (int)sizeof(T)) + (unsigned)(l8 * 16);
+    const int wrow = (threadIdx.x >> 6) * 8;  // first union row of this wave in pass 0
+    const char* Ub = reinterpret_cast<const char*>(U);
+    T x[NG][VEC];
+    auto gather = [&](int t) {
+        const unsigned cb = (unsigned)(t * B2_ROW_BYTES);
+        const bool edge = (t + 1) * CT > Dpad;
+        if (!edge) {
+#pragma unroll
+            for (int j = 0; j < NG; ++j)
+                if (wrow + j * RPP < nun8) load16(reinterpret_cast<const T*>(Ub + (gbase[j] + cb)), x[j]);
+        } else {
+            const bool ok = t * CT + l8 * VEC < Dpad;
+#pragma unroll
+            for (int j = 0; j < NG; ++j)
+                if (wrow + j * RPP < nun8 && ok) load16(reinterpret_cast<const T*>(Ub + (gbase[j] + cb)), x[j]);
+        }
+    };
+    auto deposit = [&]() {  // lanes past the last column deposit stale registers; those columns are never stored
+#pragma unroll
+        for (int j = 0; j < NG; ++j)
+            if (wrow + j * RPP < nun8) store16(reinterpret_cast<T*>(tile + (size_t)(u0 + j * RPP) * B2_ROW_BYTES) + l8 * VEC, x[j]);
+    };
+#pragma unroll
+    for (int j = 0; j < NG; ++j)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) x[j][v] = T(0);
+    MMW_STAMP(1);
+    gather(t0);
+    // the block's entries, once for all its tiles
+    for (int i = threadIdx.x; i < nmeta; i += B2_THREADS) {
+        BlkMeta<T> e;
+        e.li = (unsigned)B.lidx[m0 + i] * B2_ROW_BYTES;  // byte offset of the staged row
+        e.v = val_blk[m0 + i];
+        meta[i] = e;
+    }
+    if ((int)threadIdx.x < nrows) {
+        const int q = q0 + threadIdx.x;
+        const int b0 = B.bptr[q];
+        rowinfo[threadIdx.x] = make_int4(b0 - m0, (B.bptr[q + 1] - b0) >> 4, B.order[q], (int)B.self_li[q] * B2_ROW_BYTES);
+    }
+    MMW_STAMP(2);
+    deposit();
+    MMW_STAMP(3);
+    __syncthreads();
+    MMW_STAMP(4);
+    for (int t = t0; t < t1; ++t) {
+        if (t + 1 < t1 && !late_gather) gather(t + 1);  // next tile's rows fly while this tile is consumed from LDS
+        const int col0 = t * CT;
+        const bool colok = col0 + l8 * VEC < Dpad;
+        T dotw[VEC];  // alpha numerators of this wave's rows (lanes of group 0)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) dotw[v] = T(0);
+        for (int r = wib; r < nrows; r += B2_WAVES) {
+            T acc[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] = T(0);
+            int beg, nch, out_row, self_off;  // wave-uniform: scalar registers, scalar loop control
+            {
+                const int4 rinfo = rowinfo[r];
+                beg = __builtin_amdgcn_readfirstlane(rinfo.x);
+                nch = __builtin_amdgcn_readfirstlane(rinfo.y);
+                out_row = __builtin_amdgcn_readfirstlane(rinfo.z);
+                self_off = __builtin_amdgcn_readfirstlane(rinfo.w);
+            }
+            // The kernel is VALU-issue bound (a wave64 instruction holds its SIMD for 4 cycles; LDS runs at a third of its
+            // rate), so the loop is written for the fewest vector instructions per product: a lane group reads its two
+            // entries of a chunk with ONE broadcast ds_read_b128 (no cross-lane moves), then per entry one address add,
+            // one ds_read_b128 of the staged row and two v_pk_fma_f32.  Two chunks per step; register sets A / B alternate,
+            // each requested one step ahead (reads run up to two chunks past the row: the next row, or the block's slack).
+            const BlkMeta<T>* mp = meta + beg + 2 * g;
+            const char* tbase = tile + l8 * 16;
+            const int npair = nch >> 1;
+            Axpy16<T> sum;
+            unsigned liA[4], liB[4];
+            T vA[4], vB[4];
+            auto fetch = [&](int pair, unsigned (&li)[4], T (&vv)[4]) {
+                unsigned l0[2], l1[2];
+                T v0[2], v1[2];
+                load_meta2(mp + pair * 32, l0, v0);
+                load_meta2(mp + pair * 32 + 16, l1, v1);
+                li[0] = l0[0]; li[1] = l0[1]; li[2] = l1[0]; li[3] = l1[1];
+                vv[0] = v0[0]; vv[1] = v0[1]; vv[2] = v1[0]; vv[3] = v1[1];
+            };
+            auto consume4 = [&](const unsigned (&li)[4], const T (&vv)[4]) {
+                T xx[4][VEC];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) load16(reinterpret_cast<const T*>(tbase + li[u]), xx[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) sum.add(vv[u], xx[u]);
+            };
+            fetch(0, liA, vA);
+            int p = 0;
+            for (; p + 2 <= npair; p += 2) {
+                fetch(p + 1, liB, vB);
+                consume4(liA, vA);
+                fetch(p + 2, liA, vA);
+                consume4(liB, vB);
+            }
+            if (p < npair) {
+                fetch(p + 1, liB, vB);
+                consume4(liA, vA);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) { liA[u] = liB[u]; vA[u] = vB[u]; }
+            }
+            if (nch & 1) {  // odd tail: the first chunk of the pending pair
+                T xx[2][VEC];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) load16(reinterpret_cast<const T*>(tbase + liA[u]), xx[u]);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) sum.add(vA[u], xx[u]);
+            }
+            sum.get(acc);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                acc[v] = stride_sum(acc[v], 8);
+            }
+            if (g == 0 && colok) {
+                const size_t off = (size_t)out_row * Dpad + col0 + l8 * VEC;
+                T o[VEC];
+                if (MODE == SPMM_PLAIN) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) o[v] = (T)ascale * acc[v];
+                } else if (MODE == SPMM_LANCZOS) {
+                    T u[VEC];
+                    load16(reinterpret_cast<const T*>(tbase + self_off), u);  // U[row] is in the staged union (diagonal entry)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        o[v] = (T)ascale * acc[v];
+                        dotw[v] += u[v] * o[v];  // this wave's 2-3 rows of the tile; widened once per tile below
+                    }
+                } else if (MODE == SPMM_AXPBY) {
+                    T f[VEC], x2[VEC];
+                    load16(F + off, f);
+                    load16(X2 + off, x2);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) o[v] = (T)(ascale * (double)acc[v] + shift * (double)f[v] + inv_k * (double)x2[v]);
+                } else {
+                    T u[VEC], f[VEC];
+                    load16(reinterpret_cast<const T*>(tbase + self_off), u);
+                    load16(F + off, f);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        o[v] = (T)((ascale * (double)acc[v] - shift * (double)u[v]) * inv_k);
+                        f[v] += o[v];
+                    }
+                    store16(F + off, f);
+                }
+                store16(Out + off, o);
+            }
+        }
+        if (MODE == SPMM_LANCZOS && g == 0) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) shdot[wib * CT + l8 * VEC + v] = (double)dotw[v];
+        }
+        if (t + 1 < t1 && late_gather) gather(t + 1);
+        if (t == t0) MMW_STAMP(5);
+        __syncthreads();  // every wave is done with this tile (and shdot is complete)
+        if (t == t0) MMW_STAMP(6);
+        if (MODE == SPMM_LANCZOS) {
+            for (int c = threadIdx.x; c < CT; c += B2_THREADS)
+                if (col0 + c < Dpad) {
+                    double s = 0.0;
+                    for (int w = 0; w < B2_WAVES; ++w) s += shdot[w * CT + c];
                     partial[(size_t)rb * Dpad + col0 + c] = s;
                 }
         }
@@ -645,6 +939,59 @@ __global__ void k_lz_texp(int Dpad, int m, double inv_nsub, LanczosScalars S, co
     if (m + 1 <= 4) texp_core<4>(Dpad, c, m, inv_nsub, S);
     else if (m + 1 <= 8) texp_core<8>(Dpad, c, m, inv_nsub, S);
     else texp_core<MAX_ORDER + 1>(Dpad, c, m, inv_nsub, S);
+}
+// All Lanczos scalars of step j in ONE launch (fixed summation order, like k_colreduce):
+//   partB  holds the column sums of squares of U_j (j == 1: of the start block)  -> beta_{j-1}, sinv_j
+//   partA  holds the alpha numerators U_j . A U_j of the product just made        -> alpha_j
+// and, on the last step (j == m), the small exponentials (texp_core) of the columns this workgroup owns.
+__global__ __launch_bounds__(1024) void k_lz_scalars(int nbA, const double* __restrict__ partA, int nbB, const double* __restrict__ partB,
+                                                     int Dpad, int j, int m, double inv_nsub, double eps, LanczosScalars S,
+                                                     const ExpmPlan* __restrict__ plan) {
+    __shared__ double shA[64][17], shB[64][17];
+    if (plan) {
+        m = plan->m;
+        inv_nsub = 1.0 / plan->nsub;
+        if (j > m) return;
+    }
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double sa = 0.0, sb = 0.0;
+    if (c < Dpad) {
+        for (int b = sl; b < nbB; b += 64) sb += partB[(size_t)b * Dpad + c];
+        for (int b = sl; b < nbA; b += 64) sa += partA[(size_t)b * Dpad + c];
+    }
+    shA[sl][cl] = sa;
+    shB[sl][cl] = sb;
+    __syncthreads();
+    if (sl != 0 || c >= Dpad) return;
+    double ta = 0.0, tb = 0.0;
+#pragma unroll
+    for (int p = 0; p < 64; ++p) {
+        ta += shA[p][cl];
+        tb += shB[p][cl];
+    }
+    double si;
+    if (j == 1) {  // beta0 = ||b_c||, sinv_1
+        const double b = sqrt(tb);
+        si = b > 0.0 ? 1.0 / b : 0.0;
+        S.beta[c] = b;
+        S.sinv[1 * Dpad + c] = si;
+    } else {  // beta_{j-1} = ||U_j||, sinv_j; a column at rounding level has exhausted its Krylov space
+        const int i = j - 1;
+        const double b = sqrt(tb);
+        const double scale = fabs(S.alpha[i * Dpad + c]) + (i > 1 ? S.beta[(i - 1) * Dpad + c] : 0.0);
+        const bool dead = S.sinv[i * Dpad + c] == 0.0 || !(b > eps * scale) || !(b > 0.0);
+        si = dead ? 0.0 : 1.0 / b;
+        S.beta[i * Dpad + c] = dead ? 0.0 : b;
+        S.sinv[j * Dpad + c] = si;
+    }
+    S.alpha[j * Dpad + c] = si * si * ta;  // alpha_j = sinv_j^2 (U_j . A U_j)
+    if (j == m) {
+        __threadfence_block();
+        if (m + 1 <= 4) texp_core<4>(Dpad, c, m, inv_nsub, S);
+        else if (m + 1 <= 8) texp_core<8>(Dpad, c, m, inv_nsub, S);
+        else texp_core<MAX_ORDER + 1>(Dpad, c, m, inv_nsub, S);
+    }
 }
 // y[row,:] = sum_{j=1..m} coef[j][:] * U_j[row,:] + coef[m+1][:] * Tm[row,:]   (U_j = Ubase + (j-1)*stride),
 // one wavefront per row; optionally also d[row] = ||y_row||^2 and per-block partial sums of d (the trace).

@@ -267,13 +267,13 @@ __global__ __launch_bounds__(BLOCK) void k_sddmm(PatternDev<T> P, int Dpad, int 
                 const bool up = (lig & h) != 0;
                 T a0 = (T)(up ? s[2] : s[0]), a1 = (T)(up ? s[3] : s[1]);        // kept pair
                 const T b0 = (T)(up ? s[0] : s[2]), b1 = (T)(up ? s[1] : s[3]);  // sent pair
-                a0 += __shfl_xor(b0, h, WAVE);
-                a1 += __shfl_xor(b1, h, WAVE);
+                a0 += lane_xor(b0, h);
+                a1 += lane_xor(b1, h);
                 const bool up2 = (lig & q4) != 0;
                 T r = up2 ? a1 : a0;
                 const T snd = up2 ? a0 : a1;
-                r += __shfl_xor(snd, q4, WAVE);
-                for (int o = q4 >> 1; o > 0; o >>= 1) r += __shfl_xor(r, o, WAVE);
+                r += lane_xor(snd, q4);
+                r = group_sum(r, q4);
                 const int u = (up ? 2 : 0) + (up2 ? 1 : 0);  // the edge this lane quarter holds
                 const int e = e0 + g + u * G;
                 if (active && e < end && (lig & (q4 - 1)) == 0) {

@@ -1,6 +1,7 @@
 // C-ABI of the MI355X MMW hot path (include/mmw_hip.h) and the device-resident solver behind it.
 #include <chrono>
 #include <cstring>
+#include <map>
 #include <memory>
 
 #include "blocking.h"
@@ -151,13 +152,18 @@ template <typename T> struct Solver final : mmw_solver {
         BlkDev B;
         B.nb = HB.nb(); B.rowptr = b_rowptr.p; B.order = b_order.p; B.un_ptr = b_unptr.p; B.un_cols = b_uncols.p;
         B.bptr = b_bptr.p; B.lidx = b_lidx.p; B.self_li = b_selfli.p; B.desc = b_desc.p; B.un_fixed = b_unfixed.p;
+        B.half_tile = HB.fits_half_tile && (double)K * eng.lay.Dpad * sizeof(T) < 4.0e9 && !getenv("MMW_FULL_TILE");  // 32-bit byte offsets
         return B;
     }
     int setup_blocking() {
         const char* env = getenv("MMW_BLOCKING");
         if (env && env[0] == '0') blocking_mode = 0;
         if (!blocking_mode) return MMW_OK;
-        build_blocking(HB, K, H.l_indptr, H.l_indices, blk_max_entries<T>());
+        build_blocking(HB, K, H.l_indptr, H.l_indices, BlockingLimits{blk_max_entries<T>(), (int)sizeof(BlkMeta<T>)});
+        if (getenv("MMW_VERBOSE"))
+            fprintf(stderr, "[mmw] blocking: usable %d half-tile %d blocks %d rows/block %.1f union/block %.1f entries %lld (nnz %lld, +%.1f%% padding) sd_max %d\n",
+                    (int)HB.usable, (int)HB.fits_half_tile, HB.nb(), (double)K / std::max(1, HB.nb()), (double)HB.un_cols.size() / std::max(1, HB.nb()),
+                    (long long)HB.nent, (long long)H.nnzL(), 100.0 * ((double)HB.nent / (double)H.nnzL() - 1.0), HB.sd_max);
         if (!HB.usable) return MMW_OK;
         MMW_TRY(b_rowptr.upload(HB.blk_rowptr, st)); MMW_TRY(b_order.upload(HB.order, st)); MMW_TRY(b_unptr.upload(HB.un_ptr, st));
         MMW_TRY(b_uncols.upload(HB.un_cols, st)); MMW_TRY(b_bptr.upload(HB.bptr, st)); MMW_TRY(b_bpos.upload(HB.bpos, st));
@@ -240,6 +246,31 @@ template <typename T> struct Solver final : mmw_solver {
             fprintf(stderr, "[stamps] %d workgroups, span %.1f us; mean us per phase:", cnt, (double)(tmax - tmin) * 0.01);
             for (int k = 1; k < 10; ++k) fprintf(stderr, " p%d=%.2f", k, acc[k] / std::max(cnt, 1) * 0.01);
             fprintf(stderr, "\n");
+            // residency: workgroups whose [start, end) intervals overlap on the same (XCC, SE, SH, CU)
+            std::map<unsigned long long, std::vector<std::pair<unsigned long long, int>>> ev;
+            double wgdur = 0;
+            for (int w = 0; w < 8192; ++w) {
+                const unsigned long long* q = &h[(size_t)w * 16];
+                if (!q[0] || !q[9] || !q[10]) continue;
+                const unsigned long long cu = ((q[11] & 0xF) << 16) | (q[10] & 0xFF00);  // xcc | se, sh, cu bits of HW_ID
+                ev[cu].push_back({q[0], +1});
+                ev[cu].push_back({q[9], -1});
+                wgdur += (double)(q[9] - q[0]);
+            }
+            double t1 = 0, t2 = 0, t3 = 0;
+            for (auto& kv : ev) {
+                auto& v = kv.second;
+                std::sort(v.begin(), v.end());
+                int live = 0;
+                for (size_t i = 0; i + 1 < v.size(); ++i) {
+                    live += v[i].second;
+                    const double dt = (double)(v[i + 1].first - v[i].first);
+                    if (live == 1) t1 += dt; else if (live == 2) t2 += dt; else if (live >= 3) t3 += dt;
+                }
+            }
+            if (!ev.empty())
+                fprintf(stderr, "[stamps] %zu distinct CUs; mean workgroup %.2f us; per CU: %.1f us with 1 resident, %.1f us with 2, %.1f us with 3+\n", ev.size(),
+                        wgdur / std::max(cnt, 1) * 0.01, t1 / ev.size() * 0.01, t2 / ev.size() * 0.01, t3 / ev.size() * 0.01);
         }
         eng.use_blk = keep;
         float ms = 0;
@@ -376,6 +407,15 @@ template <typename T> struct Solver final : mmw_solver {
         pending = optimistic;
         return MMW_OK;
     }
+    int sketch_slabs() const { static const int cap = getenv("MMW_SK_SLABS") ? atoi(getenv("MMW_SK_SLABS")) : 256; return std::min(grid_rows(K), cap); }  // few slabs for the start-norm reduction
+    int launch_sketch(hipStream_t s, uint64_t seed, uint32_t it) {
+        const bool lz = eng.method == MMW_EXPM_LANCZOS;
+        const int Dpad = eng.lay.Dpad;
+        hipLaunchKernelGGL((k_sketch_rng<T>), dim3(sketch_slabs()), dim3(BLOCK), lz ? (size_t)WAVES_PER_BLOCK * Dpad * sizeof(double) : 0, s, K, D, Dpad,
+                           seed, it, eng.start_block(), lz ? eng.partial_sq.p : (double*)nullptr);
+        MMW_HIP(hipGetLastError());
+        return MMW_OK;
+    }
     int iterate_impl(int32_t n, const double* randv, uint64_t seed, bool optimistic) {
         const PatternDev<T> P = pat();
         const int gr = grid_rows(K);
@@ -413,12 +453,9 @@ template <typename T> struct Solver final : mmw_solver {
                 hipLaunchKernelGGL((k_import_block<T>), dim3(grid_elems(eng.bs)), dim3(BLOCK), 0, st, K, D, Dpad, stage64.p, eng.start_block());
                 last_was_rng = false;
             } else {
-                const bool lz = eng.method == MMW_EXPM_LANCZOS;
-                const int gs = std::min(gr, 256);  // few slabs for the start-norm reduction
-                hipLaunchKernelGGL((k_sketch_rng<T>), dim3(gs), dim3(BLOCK), lz ? (size_t)WAVES_PER_BLOCK * Dpad * sizeof(double) : 0, st, K, D, Dpad,
-                                   seed, (uint32_t)iter, eng.start_block(), lz ? eng.partial.p : (double*)nullptr);
-                eng.start_colsq_ready = lz;  // the Lanczos start norms come out of the sketch kernel
-                eng.npart_start = gs;
+                MMW_TRY(launch_sketch(st, seed, (uint32_t)iter));
+                eng.start_colsq_ready = eng.method == MMW_EXPM_LANCZOS;  // the Lanczos start norms come out of the sketch kernel
+                eng.npart_start = sketch_slabs();
                 last_was_rng = true;
                 last_seed = seed;
             }
