@@ -272,7 +272,7 @@ template <typename T> struct ExpmEngine {
                     MMW_TRY((launch_spmm<SPMM_LANCZOS>(block(j - 1), Tm.p, nullptr, ascale, 0.0, 1.0, pd, j)));
                     MMW_TRY(kbegin(KT_KRYLOV_VEC));
                     // one launch: the norms of U_j, alpha_j, and after the last product the small exponentials
-                    hipLaunchKernelGGL(k_lz_scalars, dim3((Dpad + 15) / 16), dim3(1024), 0, st, npart, partial.p, nsq, partial_sq.p, Dpad, j, m,
+                    hipLaunchKernelGGL(k_lz_scalars, dim3((Dpad + LZS_COLS - 1) / LZS_COLS), dim3(1024), 0, st, npart, partial.p, nsq, partial_sq.p, Dpad, j, m,
                                        1.0 / nsub, eps, S, pd);
                     if (j < m) {  // the last product A U_m goes straight into the combination (corrected scheme)
                         hipLaunchKernelGGL((k_lz_update<T>), dim3(gr), dim3(BLOCK), shcol, st, K, Dpad, j, Tm.p, block(j - 1),

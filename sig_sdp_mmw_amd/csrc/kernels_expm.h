@@ -944,31 +944,44 @@ __global__ void k_lz_texp(int Dpad, int m, double inv_nsub, LanczosScalars S, co
 //   partB  holds the column sums of squares of U_j (j == 1: of the start block)  -> beta_{j-1}, sinv_j
 //   partA  holds the alpha numerators U_j . A U_j of the product just made        -> alpha_j
 // and, on the last step (j == m), the small exponentials (texp_core) of the columns this workgroup owns.
+constexpr int LZS_COLS = 4;  // columns per workgroup: 32-byte slab segments, 256 slab slices in flight per column
 __global__ __launch_bounds__(1024) void k_lz_scalars(int nbA, const double* __restrict__ partA, int nbB, const double* __restrict__ partB,
                                                      int Dpad, int j, int m, double inv_nsub, double eps, LanczosScalars S,
                                                      const ExpmPlan* __restrict__ plan) {
-    __shared__ double shA[64][17], shB[64][17];
+    constexpr int SL = 1024 / LZS_COLS;
+    __shared__ double shA[SL][LZS_COLS + 1], shB[SL][LZS_COLS + 1];
+    __shared__ double s2A[16][LZS_COLS + 1], s2B[16][LZS_COLS + 1];
     if (plan) {
         m = plan->m;
         inv_nsub = 1.0 / plan->nsub;
         if (j > m) return;
     }
-    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    const int cl = threadIdx.x % LZS_COLS, sl = threadIdx.x / LZS_COLS;
+    const int c = blockIdx.x * LZS_COLS + cl;
     double sa = 0.0, sb = 0.0;
     if (c < Dpad) {
-        for (int b = sl; b < nbB; b += 64) sb += partB[(size_t)b * Dpad + c];
-        for (int b = sl; b < nbA; b += 64) sa += partA[(size_t)b * Dpad + c];
+        for (int b = sl; b < nbB; b += SL) sb += partB[(size_t)b * Dpad + c];
+        for (int b = sl; b < nbA; b += SL) sa += partA[(size_t)b * Dpad + c];
     }
     shA[sl][cl] = sa;
     shB[sl][cl] = sb;
     __syncthreads();
+    if (sl < 16) {  // fixed two-level order: 16 runs of SL/16 slices, then the 16 run totals
+        double ta = 0.0, tb = 0.0;
+        for (int p = 0; p < SL / 16; ++p) {
+            ta += shA[sl * (SL / 16) + p][cl];
+            tb += shB[sl * (SL / 16) + p][cl];
+        }
+        s2A[sl][cl] = ta;
+        s2B[sl][cl] = tb;
+    }
+    __syncthreads();
     if (sl != 0 || c >= Dpad) return;
     double ta = 0.0, tb = 0.0;
 #pragma unroll
-    for (int p = 0; p < 64; ++p) {
-        ta += shA[p][cl];
-        tb += shB[p][cl];
+    for (int p = 0; p < 16; ++p) {
+        ta += s2A[p][cl];
+        tb += s2B[p][cl];
     }
     double si;
     if (j == 1) {  // beta0 = ||b_c||, sinv_1

@@ -315,6 +315,25 @@ __global__ __launch_bounds__(BLOCK) void k_sddmm(PatternDev<T> P, int Dpad, int 
 // the block and accumulates <y_a, y_b> over the tile in registers, walking the 16 column chunks in a
 // lane-skewed order ((s + lane) mod 16) so the 16 lanes of an LDS service group touch 16 different
 // chunks = all 64 banks (conflict-free whatever rows they read).  No cross-lane reduction at all.
+// running elementwise product sum of 16-byte slices; float: two v_pk_fma_f32 per slice pair
+template <typename T> struct Dot16;
+template <> struct Dot16<float> {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 lo = {0.f, 0.f}, hi = {0.f, 0.f};
+    __device__ __forceinline__ void add(const float (&a)[4], const float (&b)[4]) {
+        lo = __builtin_elementwise_fma((f2){a[0], a[1]}, (f2){b[0], b[1]}, lo);
+        hi = __builtin_elementwise_fma((f2){a[2], a[3]}, (f2){b[2], b[3]}, hi);
+    }
+    __device__ __forceinline__ float total() const { return (lo.x + lo.y) + (hi.x + hi.y); }
+};
+template <> struct Dot16<double> {
+    double s0 = 0.0, s1 = 0.0;
+    __device__ __forceinline__ void add(const double (&a)[2], const double (&b)[2]) {
+        s0 = __builtin_fma(a[0], b[0], s0);
+        s1 = __builtin_fma(a[1], b[1], s1);
+    }
+    __device__ __forceinline__ double total() const { return s0 + s1; }
+};
 struct SdDev {
     const int* ptr;               // [nb+1]
     const unsigned short* la;
@@ -388,22 +407,16 @@ __global__ __launch_bounds__(BLK_THREADS) void k_sddmm_blk(BlkDev B, SdDev S, Pa
 #pragma unroll
         for (int k = 0; k < SD_ROUNDS; ++k) {
             if (ep[k] >= 0) {
-                T s[VEC];
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) s[v] = T(0);
+                Dot16<T> s;
 #pragma unroll
                 for (int st = 0; st < 16; ++st) {
                     const int ch = ((st + l16) & 15) * 16;
                     T xa[VEC], xb[VEC];
                     load16(reinterpret_cast<const T*>(tb + offa[k] + ch), xa);
                     load16(reinterpret_cast<const T*>(tb + offb[k] + ch), xb);
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) s[v] += xa[v] * xb[v];
+                    s.add(xa, xb);
                 }
-                double ss = 0.0;
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) ss += (double)s[v];
-                acc[k] += ss;
+                acc[k] += (double)s.total();  // one widening per entry and tile
             }
         }
         __syncthreads();
