@@ -43,6 +43,14 @@ struct HostBlocking {
     std::vector<uint16_t> sd_la, sd_lb; // local index of the row / of the column in the block's union
     std::vector<int32_t> sd_epos;       // original CSR position of the entry
     int sd_max = 0;                     // largest per-block entry count
+    // half-tile SDDMM (k_sddmm_blk2): the same entries dealt to thread slots, slot = round * 512 + thread.  The two
+    // lanes of an LDS service group that read the same 16-byte chunk hold entries of complementary row parity (both
+    // for the row side and the column side), so every read is bank-conflict free; -1 marks an idle slot.
+    std::vector<int32_t> sd2_ptr;       // [nb+1] slot ranges (multiples of 512)
+    std::vector<uint32_t> sd2_ab;       // [slots] la | lb << 16
+    std::vector<int32_t> sd2_epos;      // [slots] original CSR position, -1 idle
+    int sd2_rounds = 0;                 // most rounds any block needs
+    int un8_max = 0;                    // largest union, rounded up to 8 rows
     // one 8-int record per row block {q0, rows, m0, entries, un0, union size, chunks, 0} and the union's column
     // ids at a fixed stride (BLK_UNION per block, padded with the block's first column): a workgroup finds
     // everything it needs from its block id alone, without a chain of dependent index loads
@@ -107,6 +115,7 @@ inline std::vector<int32_t> rcm_order(int K, const std::vector<int32_t>& indptr,
 constexpr int BLK2_LDS_BYTES = 79872;
 constexpr int BLK2_HEADER_BYTES = 4864;
 constexpr int BLK2_ROW_BYTES = 128;
+constexpr int SD2_THREADS = 512;     // workgroup size of the half-tile SDDMM
 struct BlockingLimits {
     int max_entries_per_block;  // staged entries of the full-tile kernel
     int entry_bytes;            // sizeof one staged entry (offset + value)
@@ -208,6 +217,10 @@ inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& i
     B.bptr.assign(K + 1, 0);
     B.self_li.assign(K, 0);
     B.sd_ptr.assign(1, 0);
+    B.sd2_ptr.assign(1, 0);
+    B.sd2_ab.clear(); B.sd2_epos.clear();
+    B.sd2_rounds = 0;
+    B.un8_max = 0;
     B.sd_la.clear(); B.sd_lb.clear(); B.sd_epos.clear();
     B.sd_max = 0;
     B.lidx.clear();
@@ -263,6 +276,49 @@ inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& i
         }
         B.sd_ptr.push_back((int32_t)B.sd_epos.size());
         B.sd_max = std::max(B.sd_max, B.sd_ptr[b + 1] - B.sd_ptr[b]);
+        {   // slots of the half-tile SDDMM
+            struct Ed { uint16_t a, b; int32_t e; };
+            std::vector<Ed> ee, oo, mx;  // both rows even / both odd / mixed (stored as even row first)
+            for (int i = B.sd_ptr[b]; i < B.sd_ptr[b + 1]; ++i) {
+                Ed d{B.sd_la[i], B.sd_lb[i], B.sd_epos[i]};
+                const int pa = d.a & 1, pb = d.b & 1;
+                if (pa == pb) (pa ? oo : ee).push_back(d);
+                else {
+                    if (pa) std::swap(d.a, d.b);  // the dot product is symmetric
+                    mx.push_back(d);
+                }
+            }
+            // pairs (first lane, second lane): (EE, OO) and (mixed even-first, mixed odd-first); leftovers pair with idle
+            std::vector<std::pair<Ed, Ed>> pairs;
+            const Ed idle{0, 0, -1};
+            const size_t nz = std::max(ee.size(), oo.size());
+            for (size_t i = 0; i < nz; ++i) pairs.push_back({i < ee.size() ? ee[i] : idle, i < oo.size() ? oo[i] : idle});
+            for (size_t i = 0; i < mx.size(); i += 2) {
+                Ed second = idle;
+                if (i + 1 < mx.size()) { second = mx[i + 1]; std::swap(second.a, second.b); }
+                pairs.push_back({mx[i], second});
+            }
+            const int per_round = SD2_THREADS / 2;
+            const int rounds = std::max(1, (int)((pairs.size() + per_round - 1) / per_round));
+            B.sd2_rounds = std::max(B.sd2_rounds, rounds);
+            const size_t base = B.sd2_ab.size();
+            B.sd2_ab.resize(base + (size_t)rounds * SD2_THREADS, 0u);
+            B.sd2_epos.resize(base + (size_t)rounds * SD2_THREADS, -1);
+            for (size_t i = 0; i < pairs.size(); ++i) {
+                const int round = (int)(i / per_round), pi = (int)(i % per_round);
+                const int wave = pi / 32, j = pi % 32;          // 32 pairs per wave: 16 per 32-lane half
+                const int half = j / 16, l = j % 16;
+                const int lane1 = half * 32 + l, lane2 = lane1 + (l < 8 ? 24 : 8);
+                const Ed* d[2] = {&pairs[i].first, &pairs[i].second};
+                const int lanes[2] = {lane1, lane2};
+                for (int w = 0; w < 2; ++w) {
+                    const size_t slot = base + (size_t)round * SD2_THREADS + (size_t)wave * 64 + lanes[w];
+                    B.sd2_ab[slot] = (uint32_t)d[w]->a | ((uint32_t)d[w]->b << 16);
+                    B.sd2_epos[slot] = d[w]->e;
+                }
+            }
+            B.sd2_ptr.push_back((int32_t)B.sd2_ab.size());
+        }
     }
     B.nent = w;
     B.desc.assign((size_t)B.nb() * 8, 0);
@@ -273,6 +329,8 @@ inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& i
         int32_t* d = &B.desc[(size_t)b * 8];
         d[0] = q0; d[1] = q1 - q0; d[2] = B.bptr[q0]; d[3] = B.bptr[q1] - B.bptr[q0]; d[4] = B.un_ptr[b]; d[5] = nun;
         d[6] = (B.bptr[q1] - B.bptr[q0]) / BLK_CHUNK;
+        d[7] = B.sd2_ptr[b];
+        B.un8_max = std::max(B.un8_max, (nun + 7) & ~7);
         for (int u = 0; u < BLK_UNION; ++u) B.un_fixed[(size_t)b * BLK_UNION + u] = B.un_cols[B.un_ptr[b] + (u < nun ? u : 0)];
     }
     B.reuse = B.un_cols.empty() ? 0.0 : (double)nnz / (double)B.un_cols.size();

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, in
         if (MODE == SPMM_TAYLOR) shift = plan->mu / plan->nsub;
     }
     constexpr int RPP = BLK_THREADS / 16;                // union rows gathered per pass
-    constexpr int NG = BLK_UNION_ROWS / RPP;             // gathers per thread
+    constexpr int NG = (BLK_UNION_ROWS + RPP - 1) / RPP;             // gathers per thread
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* tile = reinterpret_cast<T*>(smem_raw);                                                        // [BLK_UNION_ROWS][CT]
     BlkMeta<T>* meta = reinterpret_cast<BlkMeta<T>*>(smem_raw + (size_t)BLK_UNION_ROWS * BLK_TILE_BYTES);  // [entries]
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, in
     // this thread's share of the union (same rows for every tile)
     unsigned gbase[NG];  // element offsets of the union rows (K * Dpad < 2^32); live only until they are parked in LDS
 #pragma unroll
-    for (int j = 0; j < NG; ++j) gbase[j] = (unsigned)B.un_fixed[(size_t)rb * BLK_UNION_ROWS + u0 + j * RPP] * (unsigned)Dpad;
+    for (int j = 0; j < NG; ++j) gbase[j] = (unsigned)B.un_fixed[(size_t)rb * BLK_UNION_ROWS + min(u0 + j * RPP, BLK_UNION_ROWS - 1)] * (unsigned)Dpad;
     T x[NG][VEC];
     auto gather0 = [&](int t) {  // first tile: offsets still in registers
         const int c = t * CT + l16 * VEC;
@@ -526,7 +526,7 @@ void k_spmm_blk2(BlkDev B, int Dpad, int ntiles, int tpw, const T* __restrict__ 
     const bool late_gather = (tpw & 0x100) != 0;
     tpw &= 0xFF;
     constexpr int RPP = B2_THREADS / 8;        // union rows gathered per pass
-    constexpr int NG = BLK_UNION_ROWS / RPP;   // gathers per thread
+    constexpr int NG = (BLK_UNION_ROWS + RPP - 1) / RPP;   // gathers per thread
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     int4* rowinfo = reinterpret_cast<int4*>(smem_raw);                          // [64]
     double* shdot = reinterpret_cast<double*>(smem_raw + 1024 + 1792);         // [B2_WAVES][CT]
@@ -553,7 +553,7 @@ void k_spmm_blk2(BlkDev B, int Dpad, int ntiles, int tpw, const T* __restrict__ 
     unsigned gbase[NG];
 #pragma unroll
     for (int j = 0; j < NG; ++j)
-        gbase[j] = (unsigned)B.un_fixed[(size_t)rb * BLK_UNION_ROWS + u0 + j * RPP] * (unsigned)(Dpad * (int)sizeof(T)) + (unsigned)(l8 * 16);
+        gbase[j] = (unsigned)B.un_fixed[(size_t)rb * BLK_UNION_ROWS + min(u0 + j * RPP, BLK_UNION_ROWS - 1)] * (unsigned)(Dpad * (int)sizeof(T)) + (unsigned)(l8 * 16);
     const int wrow = (threadIdx.x >> 6) * 8;  // first union row of this wave in pass 0
     const char* Ub = reinterpret_cast<const char*>(U);
     T x[NG][VEC];

@@ -5,6 +5,7 @@
 //   averaging (mmw.py:77-78) is folded into the producers of X and Y.
 // Reductions are wavefront shuffles + fixed-order per-block slabs (bitwise reproducible, no atomics).
 #pragma once
+#include "blocking.h"
 #include "device_utils.h"
 #include "kernels_expm.h"
 
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_sddmm_blk(BlkDev B, SdDev S, Pa
     constexpr int VEC = V16<T>::N;
     constexpr int CT = BLK_TILE_BYTES / (int)sizeof(T);
     constexpr int RPP = BLK_THREADS / 16;
-    constexpr int NG = BLK_UNION_ROWS / RPP;
+    constexpr int NG = (BLK_UNION_ROWS + RPP - 1) / RPP;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* tile = reinterpret_cast<T*>(smem_raw);
     __shared__ double sh[BLK_WAVES];
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_sddmm_blk(BlkDev B, SdDev S, Pa
     const int nun = B.desc[(size_t)rb * 8 + 5];
     unsigned gbase[NG];  // element offsets of the union rows (K * Dpad < 2^32)
 #pragma unroll
-    for (int j = 0; j < NG; ++j) gbase[j] = (unsigned)B.un_fixed[(size_t)rb * BLK_UNION_ROWS + u0 + j * RPP] * (unsigned)Dpad;
+    for (int j = 0; j < NG; ++j) gbase[j] = (unsigned)B.un_fixed[(size_t)rb * BLK_UNION_ROWS + min(u0 + j * RPP, BLK_UNION_ROWS - 1)] * (unsigned)Dpad;
     T x[NG][VEC];
     auto gather = [&](int t) {
         const int c = t * CT + l16 * VEC;
@@ -448,6 +449,151 @@ __global__ __launch_bounds__(BLK_THREADS) void k_sddmm_blk(BlkDev B, SdDev S, Pa
     }
 }
 
+// ---- the same on 128-byte half tiles, up to three workgroups per CU ---------------------------------
+// 512 threads, LDS = the union's rows at 128 B (<= 56 KiB), so two or three workgroups share a CU and one computes
+// while another waits on its gathers or barriers.  Thread-per-entry as above, 8 column chunks walked in the
+// lane-skewed order (s + lane) mod 8.  With 128-byte rows a chunk of an even and of an odd staged row lie in different
+// bank halves, and the host deals the entries so that the two lanes of a ds_read_b128 service group that read the same
+// chunk hold rows of opposite parity (blocking.h, sd2_*): conflict-free for both operands.
+struct Sd2Dev {
+    const int* ptr;            // [nb+1] slot ranges
+    const unsigned* ab;        // la | lb << 16
+    const int* epos;           // -1 idle
+};
+constexpr int SD2_ROUNDS = 5;
+template <typename T>
+__global__ __launch_bounds__(SD2_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6)))  // <= 80 VGPRs: three workgroups per CU
+void k_sddmm_blk2(BlkDev B, Sd2Dev S, PatternDev<T> P, int Dpad, int ntiles,
+                                                            const T* __restrict__ Yb, const T* __restrict__ d,
+                                                            const double* __restrict__ tr_part, int ntr, T* __restrict__ xval,
+                                                            T* __restrict__ xavg, int accumulate, unsigned long long* __restrict__ stamps) {
+    constexpr int VEC = V16<T>::N;
+    constexpr int CT = B2_ROW_BYTES / (int)sizeof(T);
+#define MMW_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    MMW_STAMP(0);
+    if (stamps && threadIdx.x == 0) {
+        stamps[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_getreg(63492);
+        stamps[(size_t)blockIdx.x * 16 + 11] = __builtin_amdgcn_s_getreg(63508);
+    }
+    constexpr int RPP = SD2_THREADS / 8;
+    constexpr int NG = (BLK_UNION_ROWS + RPP - 1) / RPP;
+    constexpr int NW = SD2_THREADS / WAVE;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char* tile = smem_raw;
+    __shared__ double sh[NW];
+    double tsum = 0.0;
+    for (int i = threadIdx.x; i < ntr; i += SD2_THREADS) tsum += tr_part[i];
+    tsum = block_sum(tsum, sh);
+    const double tr = tsum / (double)P.K;
+    const int per = (B.nb + 7) / 8;
+    const int rb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (rb >= B.nb) return;
+    const int l8 = threadIdx.x & 7, u0 = threadIdx.x >> 3;
+    const int nun8 = (B.desc[(size_t)rb * 8 + 5] + 7) & ~7;
+    unsigned gbase[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j)
+        gbase[j] = (unsigned)B.un_fixed[(size_t)rb * BLK_UNION_ROWS + min(u0 + j * RPP, BLK_UNION_ROWS - 1)] * (unsigned)(Dpad * (int)sizeof(T)) + (unsigned)(l8 * 16);
+    const int wrow = (threadIdx.x >> 6) * 8;
+    const char* Ub = reinterpret_cast<const char*>(Yb);
+    T x[NG][VEC];
+#pragma unroll
+    for (int j = 0; j < NG; ++j)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) x[j][v] = T(0);
+    auto gather = [&](int t) {
+        const unsigned cb = (unsigned)(t * B2_ROW_BYTES);
+        const bool ok = t * CT + l8 * VEC < Dpad;  // only the last, partial tile tests lanes
+#pragma unroll
+        for (int j = 0; j < NG; ++j)
+            if (wrow + j * RPP < nun8 && ok) load16(reinterpret_cast<const T*>(Ub + (gbase[j] + cb)), x[j]);
+    };
+    auto deposit = [&](bool full) {  // columns past Dpad are staged as zeros: every lane reads every chunk of its rows
+#pragma unroll
+        for (int j = 0; j < NG; ++j)
+            if (wrow + j * RPP < nun8) {
+                if (!full) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) x[j][v] = T(0);
+                }
+                store16(reinterpret_cast<T*>(tile + (size_t)(u0 + j * RPP) * B2_ROW_BYTES) + l8 * VEC, x[j]);
+            }
+    };
+    MMW_STAMP(1);
+    gather(0);
+    const int s0 = S.ptr[rb], rounds = (S.ptr[rb + 1] - s0) / SD2_THREADS;
+    unsigned ab[SD2_ROUNDS];  // staged row indices of the entry's two rows, packed (registers are the budget here)
+    int ep[SD2_ROUNDS];
+    T acc[SD2_ROUNDS];
+#pragma unroll
+    for (int k = 0; k < SD2_ROUNDS; ++k) {
+        acc[k] = T(0);
+        ep[k] = -1;
+        ab[k] = 0;
+        if (k < rounds) {
+            ab[k] = S.ab[s0 + k * SD2_THREADS + threadIdx.x];
+            ep[k] = S.epos[s0 + k * SD2_THREADS + threadIdx.x];
+        }
+    }
+    MMW_STAMP(2);
+    deposit(l8 * VEC < Dpad);
+    MMW_STAMP(3);
+    __syncthreads();
+    MMW_STAMP(4);
+    const int skew = threadIdx.x & 7;
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) gather(t + 1);
+#pragma unroll
+        for (int k = 0; k < SD2_ROUNDS; ++k) {
+            if (k < rounds && ep[k] >= 0) {
+                Dot16<T> s;
+                const char* ra = tile + (ab[k] & 0xFFFFu) * B2_ROW_BYTES;
+                const char* rb_ = tile + (ab[k] >> 16) * B2_ROW_BYTES;
+#pragma unroll 4
+                for (int st = 0; st < 8; ++st) {  // 8 staged-row reads in flight (the register budget allows no more)
+                    const int ch = ((st + skew) & 7) * 16;
+                    T xa[VEC], xb[VEC];
+                    load16(reinterpret_cast<const T*>(ra + ch), xa);
+                    load16(reinterpret_cast<const T*>(rb_ + ch), xb);
+                    s.add(xa, xb);
+                }
+                acc[k] += s.total();
+            }
+        }
+        if (t == 0) MMW_STAMP(5);
+        __syncthreads();
+        if (t == 0) MMW_STAMP(6);
+        if (t + 1 < ntiles) {
+            deposit((t + 1) * CT + l8 * VEC < Dpad);
+            if (t == 0) MMW_STAMP(7);
+            __syncthreads();
+            if (t == 0) MMW_STAMP(8);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < SD2_ROUNDS; ++k)
+        if (ep[k] >= 0) {
+            const T xv = (T)((double)acc[k] / tr);
+            const int e = ep[k], me = P.mirror[e];
+            xval[e] = xv;
+            xval[me] = xv;
+            if (accumulate) {
+                xavg[e] += xv;
+                xavg[me] += xv;
+            }
+        }
+    const int q0 = B.rowptr[rb], q1 = B.rowptr[rb + 1];
+    for (int q = q0 + threadIdx.x; q < q1; q += SD2_THREADS) {
+        const int row = B.order[q];
+        const int dp = P.diag_pos[row];
+        const T xd = (T)((double)d[row] / tr);
+        xval[dp] = xd;
+        if (accumulate) xavg[dp] += xd;
+    }
+    MMW_STAMP(9);
+#undef MMW_STAMP
+}
+
 // ---- on-device Gaussian sketch: rows of unit 2-norm (mmw.py:226-227) -----------------------------
 // One wavefront per row, one pass: every lane draws its 16 bytes of the row (4 floats / 2 doubles) per
 // step from Philox4x32-10 keyed by (seed; row, column group, iteration), keeps them in registers, the
@@ -457,10 +603,11 @@ __device__ __forceinline__ void normals16(const uint32_t (&w)[4], float (&n)[4])
     const float u2 = (float)(w[1] >> 8) * 5.9604644775390625e-8f;
     const float u3 = (float)((w[2] >> 8) + 1u) * 5.9604644775390625e-8f;
     const float u4 = (float)(w[3] >> 8) * 5.9604644775390625e-8f;
-    const float r1 = sqrtf(-2.0f * __logf(u1)), r2 = sqrtf(-2.0f * __logf(u3));
-    float s1, c1, s2, c2;
-    sincospif(2.0f * u2, &s1, &c1);
-    sincospif(2.0f * u4, &s2, &c2);
+    // hardware transcendentals: v_log_f32, v_sqrt_f32 and v_sin/cos_f32, whose argument is in revolutions (u in [0,1))
+    const float r1 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // sqrt(-2 ln u) = sqrt(-2 ln2 log2 u)
+    const float r2 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u3));
+    const float s1 = __builtin_amdgcn_sinf(u2), c1 = __builtin_amdgcn_cosf(u2);
+    const float s2 = __builtin_amdgcn_sinf(u4), c2 = __builtin_amdgcn_cosf(u4);
     n[0] = r1 * c1; n[1] = r1 * s1; n[2] = r2 * c2; n[3] = r2 * s2;
 }
 __device__ __forceinline__ void normals16(const uint32_t (&w)[4], double (&n)[2]) { box_muller(w, n[0], n[1]); }
@@ -474,14 +621,14 @@ __global__ __launch_bounds__(BLOCK) void k_sketch_rng(int K, int D, int Dpad, ui
     double* shc = reinterpret_cast<double*>(smem_raw);  // [WAVES_PER_BLOCK][Dpad] when colsq_part
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int ngroups = Dpad / VEC;
-    double csq[NS][VEC];
+    T csq[NS][VEC];  // a wave sums a handful of unit-norm rows: T is enough, widened once at the end
 #pragma unroll
     for (int i = 0; i < NS; ++i)
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) csq[i][v] = 0.0;
+        for (int v = 0; v < VEC; ++v) csq[i][v] = T(0);
     for (int row = blockIdx.x * WAVES_PER_BLOCK + wib; row < K; row += gridDim.x * WAVES_PER_BLOCK) {
         T n[NS][VEC];
-        double ss = 0.0;
+        T ssl = T(0);
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             const int p = lane + WAVE * i;
@@ -494,11 +641,11 @@ __global__ __launch_bounds__(BLOCK) void k_sketch_rng(int K, int D, int Dpad, ui
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
                     if (p * VEC + v >= D) n[i][v] = T(0);
-                    ss += (double)n[i][v] * (double)n[i][v];
+                    ssl += n[i][v] * n[i][v];
                 }
             }
         }
-        ss = wave_sum(ss);
+        const double ss = wave_sum((double)ssl);
         const T inv = (T)(ss > 0.0 ? 1.0 / sqrt(ss) : 0.0);
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
@@ -507,7 +654,7 @@ __global__ __launch_bounds__(BLOCK) void k_sketch_rng(int K, int D, int Dpad, ui
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
                     n[i][v] *= inv;
-                    csq[i][v] += (double)n[i][v] * (double)n[i][v];
+                    csq[i][v] += n[i][v] * n[i][v];
                 }
                 store16(R + (size_t)row * Dpad + (size_t)p * VEC, n[i]);
             }
@@ -519,7 +666,7 @@ __global__ __launch_bounds__(BLOCK) void k_sketch_rng(int K, int D, int Dpad, ui
             const int p = lane + WAVE * i;
             if (p < ngroups)
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) shc[wib * Dpad + p * VEC + v] = csq[i][v];
+                for (int v = 0; v < VEC; ++v) shc[wib * Dpad + p * VEC + v] = (double)csq[i][v];
         }
         __syncthreads();
         for (int c = threadIdx.x; c < Dpad; c += BLOCK) {

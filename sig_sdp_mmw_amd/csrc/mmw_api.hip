@@ -54,6 +54,9 @@ template <typename T> struct Solver final : mmw_solver {
     DevBuf<unsigned short> b_lidx, b_selfli, b_sdla, b_sdlb;
     DevBuf<int> b_sdptr, b_sdepos, b_desc, b_unfixed;
     bool sddmm_blk = false;
+    DevBuf<int> b_sd2ptr, b_sd2epos;
+    DevBuf<unsigned> b_sd2ab;
+    bool sddmm_blk2 = false;  // half-tile SDDMM (k_sddmm_blk2)
     DevBuf<T> lval_blk;
     int blocking_mode = 1;  // 1: use when profitable, 0: never
     // optimistic (no per-iteration readback) batches: snapshot for the rare replay
@@ -176,6 +179,12 @@ template <typename T> struct Solver final : mmw_solver {
             MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sddmm_blk<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
             sddmm_blk = true;
         }
+        if (HB.sd2_rounds <= SD2_ROUNDS && (double)K * eng.lay.Dpad * sizeof(T) < 4.0e9 && !getenv("MMW_FULL_TILE")) {
+            MMW_TRY(b_sd2ptr.upload(HB.sd2_ptr, st)); MMW_TRY(b_sd2ab.upload(HB.sd2_ab, st)); MMW_TRY(b_sd2epos.upload(HB.sd2_epos, st));
+            MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sddmm_blk2<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        HB.un8_max * B2_ROW_BYTES));
+            sddmm_blk2 = true;
+        }
         MMW_HIP(hipStreamSynchronize(st));
         extras.fac.set_blocking(blkdev(), b_bepos.p, HB.nent);
         return eng.enable_blocking(blkdev(), lval_blk.p);
@@ -197,40 +206,11 @@ template <typename T> struct Solver final : mmw_solver {
         timing = enabled != 0;
         return MMW_OK;
     }
-    // SpMM micro-benchmark on the current L values: Tm = 0.5 * L * start_block, `reps` launches
-    int bench_spmm(int blocked, int reps, double* avg_us) override {
-        if (host_only) return fail(MMW_ERR_STATE, "host-only handle");
-        MMW_HIP(hipSetDevice(device));
-        if (blocked && !HB.usable) return fail(MMW_ERR_STATE, "no locality blocking for this pattern");
-        MMW_TRY(sync());
-        hipLaunchKernelGGL((k_sketch_rng<T>), dim3(grid_rows(K)), dim3(BLOCK), 0, st, K, D, eng.lay.Dpad, 99ull, 0u, eng.start_block(), (double*)nullptr);
-        const bool keep = eng.use_blk;
-        eng.use_blk = blocked != 0;
-        DevBuf<unsigned long long> stamps;
-        const bool want_stamps = blocked && getenv("MMW_STAMPS");
-        if (want_stamps) {
-            MMW_TRY(stamps.alloc((size_t)16 * 8192));
-            MMW_HIP(hipMemsetAsync(stamps.p, 0, (size_t)16 * 8192 * sizeof(unsigned long long), st));
-        }
-        hipEvent_t e0, e1;
-        MMW_HIP(hipEventCreate(&e0));
-        MMW_HIP(hipEventCreate(&e1));
-        const bool lz = getenv("MMW_BENCH_LANCZOS") != nullptr;  // time the Lanczos epilogue (alpha partials) instead of the plain product
-        auto one = [&]() {
-            return lz ? eng.template launch_spmm<SPMM_LANCZOS>(eng.start_block(), eng.Tm.p, nullptr, 0.5, 0.0, 1.0)
-                      : eng.template launch_spmm<SPMM_PLAIN>(eng.start_block(), eng.Tm.p, nullptr, 0.5, 0.0, 1.0);
-        };
-        int rc = one();  // warm
-        MMW_HIP(hipEventRecord(e0, st));
-        for (int r = 0; r < reps && rc == MMW_OK; ++r) rc = one();
-        MMW_HIP(hipEventRecord(e1, st));
-        MMW_HIP(hipStreamSynchronize(st));
-        if (want_stamps) {
-            g_blk_stamps = stamps.p;
-            rc = one();
-            g_blk_stamps = nullptr;
+    // diagnostic: per-workgroup phase stamps written by a blocked kernel (16 slots per workgroup, slot 9 = end,
+    // 10 = HW_ID, 11 = XCC_ID): mean time per phase and how many workgroups were resident per CU
+    int dump_stamps(const unsigned long long* dev) {
             std::vector<unsigned long long> h((size_t)16 * 8192);
-            MMW_HIP(hipMemcpyAsync(h.data(), stamps.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            MMW_HIP(hipMemcpyAsync(h.data(), dev, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
             MMW_HIP(hipStreamSynchronize(st));
             double acc[10] = {0};
             int cnt = 0;
@@ -271,6 +251,41 @@ template <typename T> struct Solver final : mmw_solver {
             if (!ev.empty())
                 fprintf(stderr, "[stamps] %zu distinct CUs; mean workgroup %.2f us; per CU: %.1f us with 1 resident, %.1f us with 2, %.1f us with 3+\n", ev.size(),
                         wgdur / std::max(cnt, 1) * 0.01, t1 / ev.size() * 0.01, t2 / ev.size() * 0.01, t3 / ev.size() * 0.01);
+        return MMW_OK;
+    }
+    // SpMM micro-benchmark on the current L values: Tm = 0.5 * L * start_block, `reps` launches
+    int bench_spmm(int blocked, int reps, double* avg_us) override {
+        if (host_only) return fail(MMW_ERR_STATE, "host-only handle");
+        MMW_HIP(hipSetDevice(device));
+        if (blocked && !HB.usable) return fail(MMW_ERR_STATE, "no locality blocking for this pattern");
+        MMW_TRY(sync());
+        hipLaunchKernelGGL((k_sketch_rng<T>), dim3(grid_rows(K)), dim3(BLOCK), 0, st, K, D, eng.lay.Dpad, 99ull, 0u, eng.start_block(), (double*)nullptr);
+        const bool keep = eng.use_blk;
+        eng.use_blk = blocked != 0;
+        DevBuf<unsigned long long> stamps;
+        const bool want_stamps = blocked && getenv("MMW_STAMPS");
+        if (want_stamps) {
+            MMW_TRY(stamps.alloc((size_t)16 * 8192));
+            MMW_HIP(hipMemsetAsync(stamps.p, 0, (size_t)16 * 8192 * sizeof(unsigned long long), st));
+        }
+        hipEvent_t e0, e1;
+        MMW_HIP(hipEventCreate(&e0));
+        MMW_HIP(hipEventCreate(&e1));
+        const bool lz = getenv("MMW_BENCH_LANCZOS") != nullptr;  // time the Lanczos epilogue (alpha partials) instead of the plain product
+        auto one = [&]() {
+            return lz ? eng.template launch_spmm<SPMM_LANCZOS>(eng.start_block(), eng.Tm.p, nullptr, 0.5, 0.0, 1.0)
+                      : eng.template launch_spmm<SPMM_PLAIN>(eng.start_block(), eng.Tm.p, nullptr, 0.5, 0.0, 1.0);
+        };
+        int rc = one();  // warm
+        MMW_HIP(hipEventRecord(e0, st));
+        for (int r = 0; r < reps && rc == MMW_OK; ++r) rc = one();
+        MMW_HIP(hipEventRecord(e1, st));
+        MMW_HIP(hipStreamSynchronize(st));
+        if (want_stamps) {
+            g_blk_stamps = stamps.p;
+            rc = one();
+            g_blk_stamps = nullptr;
+            MMW_TRY(dump_stamps(stamps.p));
         }
         eng.use_blk = keep;
         float ms = 0;
@@ -467,7 +482,22 @@ template <typename T> struct Solver final : mmw_solver {
             MMW_TRY(kt.begin(KT_SDDMM));
             if (eng.method != MMW_EXPM_LANCZOS)
                 hipLaunchKernelGGL((k_rownorm2<T>), dim3(gr), dim3(BLOCK), 0, st, K, Dpad, Xh.p, drow.p, tr_part.p);
-            if (sddmm_blk && eng.use_blk) {
+            if (sddmm_blk2 && eng.use_blk) {
+                unsigned long long* sd_stamps = nullptr;  // MMW_SD_STAMPS=1: phase stamps of the last iteration's SDDMM
+                DevBuf<unsigned long long> stamp_buf;
+                if (it + 1 == n && getenv("MMW_SD_STAMPS")) {
+                    MMW_TRY(stamp_buf.alloc((size_t)16 * 8192));
+                    MMW_HIP(hipMemsetAsync(stamp_buf.p, 0, (size_t)16 * 8192 * sizeof(unsigned long long), st));
+                    sd_stamps = stamp_buf.p;
+                }
+                Sd2Dev S;
+                S.ptr = b_sd2ptr.p; S.ab = b_sd2ab.p; S.epos = b_sd2epos.p;
+                constexpr int CT2 = B2_ROW_BYTES / (int)sizeof(T);
+                const int per = (HB.nb() + 7) / 8;
+                hipLaunchKernelGGL((k_sddmm_blk2<T>), dim3(per * 8), dim3(SD2_THREADS), (size_t)HB.un8_max * B2_ROW_BYTES, st, blkdev(), S, P, Dpad,
+                                   (Dpad + CT2 - 1) / CT2, Xh.p, drow.p, tr_part.p, gr, xval.p, xavg.p, acc, sd_stamps);
+                if (sd_stamps) MMW_TRY(dump_stamps(sd_stamps));
+            } else if (sddmm_blk && eng.use_blk) {
                 SdDev S;
                 S.ptr = b_sdptr.p; S.la = b_sdla.p; S.lb = b_sdlb.p; S.epos = b_sdepos.p;
                 constexpr int CT = BLK_TILE_BYTES / (int)sizeof(T);

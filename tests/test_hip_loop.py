@@ -168,19 +168,24 @@ def test_blocked_and_generic_spmm_agree(run_case, monkeypatch):
     state = state_from(g)
     Z, nit, eta = int(g["Z"]), int(g["nit"]), float(g["eta"])
     outs = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("MMW_BLOCKING", mode)
+    for mode in ("1", "full", "0"):  # half-tile kernel (two workgroups per CU), full-tile kernel, generic gather
+        monkeypatch.setenv("MMW_BLOCKING", "0" if mode == "0" else "1")
+        if mode == "full":
+            monkeypatch.setenv("MMW_FULL_TILE", "1")
+        else:
+            monkeypatch.delenv("MMW_FULL_TILE", raising=False)
         for dtype in (_lib.F64, _lib.F32):
             s = _lib.Solver(Z, state, nit, eta, dtype=dtype)
             info = s.read(_lib.F_BLOCKING)
-            assert info[0] == (1.0 if mode == "1" else 0.0), (name, info)
+            assert info[0] == (0.0 if mode == "0" else 1.0), (name, info)
             s.set_expm(_lib.EXPM_LANCZOS, 16, 1e-13 if dtype == _lib.F64 else 1e-7)
             s.iterate(nit, g["randv"][:nit])
             outs[(mode, dtype)] = (s.read(_lib.F_XHALF), s.read(_lib.F_LVAL))
             s.close()
     for dtype, bar in ((_lib.F64, 1e-12), (_lib.F32, 2e-5)):
-        assert relerr(outs[("1", dtype)][0], outs[("0", dtype)][0]) < bar
-        assert relerr(outs[("1", dtype)][1], outs[("0", dtype)][1]) < bar
+        for mode in ("1", "full"):
+            assert relerr(outs[(mode, dtype)][0], outs[("0", dtype)][0]) < bar
+            assert relerr(outs[(mode, dtype)][1], outs[("0", dtype)][1]) < bar
 
 
 @pytest.mark.parametrize("kind", ["journal", "er"])
