@@ -9,7 +9,8 @@ constexpr int WAVE = 64;
 constexpr int BLOCK = 256;               // 4 waves per workgroup
 constexpr int WAVES_PER_BLOCK = BLOCK / WAVE;
 constexpr int MAX_ORDER = 16;            // Krylov order cap per substep
-constexpr int MAX_PART = 1024;           // upper bound on per-block partial slabs
+constexpr int MAX_PART = 1024;           // upper bound on per-block partial slabs (Dpad-wide rows of doubles)
+constexpr int ROW_GRID_MAX = 4096;       // upper bound on the grid of one-wave-per-row kernels (scalar partials per block)
 
 template <typename T> struct V16;
 template <> struct V16<float> {

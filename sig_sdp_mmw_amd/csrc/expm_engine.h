@@ -94,7 +94,7 @@ template <typename T> struct ExpmEngine {
     BlockLayout lay{};
     int method = MMW_EXPM_LANCZOS, max_order = 8;
     double tol = 1e-9;
-    int nblk = 1;
+    int nblk = 1, nwide = 1;
     const int* indptr = nullptr;
     const int* col = nullptr;
     const T* val = nullptr;
@@ -134,7 +134,8 @@ template <typename T> struct ExpmEngine {
         std::string err;
         if (make_layout(D, V16<T>::N, lay, err) != MMW_OK) return fail(MMW_ERR_ARG, err);
         bs = (size_t)K * lay.Dpad;
-        nblk = grid_rows(K);
+        nblk = grid_slabs(K);   // generic SpMM (alpha slabs)
+        nwide = grid_rows(K);   // row kernels with scalar partials (1-norm bound, combination)
         ublocks = 0;
         MMW_TRY(ensure_blocks(4));  // the basis grows on demand: the MMW loop rarely needs more than 3 vectors
         MMW_TRY(Tm.alloc(bs));
@@ -143,7 +144,7 @@ template <typename T> struct ExpmEngine {
         npart = nblk;
         MMW_TRY(colsum.alloc(lay.Dpad));
         MMW_TRY(scal.alloc((size_t)4 * (MAX_ORDER + 2) * lay.Dpad));
-        MMW_TRY(rho_part.alloc(MAX_PART));
+        MMW_TRY(rho_part.alloc(ROW_GRID_MAX));
         MMW_TRY(trace_own.alloc(MAX_PART));
         MMW_TRY(plan_d.alloc(1));
         MMW_TRY(viol_d.alloc(1));
@@ -215,8 +216,8 @@ template <typename T> struct ExpmEngine {
             trace_part = trace_own.p;
             ntrace = g;
         }
-        hipLaunchKernelGGL((k_rowabs<T>), dim3(nblk), dim3(BLOCK), 0, st, K, indptr, col, val, ascale, trace_part, ntrace, rho_part.p);
-        hipLaunchKernelGGL(k_plan, dim3(1), dim3(BLOCK), 0, st, K, method, max_order, tol, ascale, rho_part.p, nblk, trace_part, ntrace, plan_d.p,
+        hipLaunchKernelGGL((k_rowabs<T>), dim3(nwide), dim3(BLOCK), 0, st, K, indptr, col, val, ascale, trace_part, ntrace, rho_part.p);
+        hipLaunchKernelGGL(k_plan, dim3(1), dim3(BLOCK), 0, st, K, method, max_order, tol, ascale, rho_part.p, nwide, trace_part, ntrace, plan_d.p,
                            m_launch, viol_d.p);
         MMW_HIP(hipGetLastError());
         if (m_launch > 0) return MMW_OK;
@@ -258,7 +259,7 @@ template <typename T> struct ExpmEngine {
             }
             if (method == MMW_EXPM_LANCZOS) {
                 LanczosScalars S = scalars();
-                const int gr = grid_rows(K * 4);  // k_colsq / k_lz_update stride rows by workgroup
+                const int gr = grid_slabs(K * 4);  // k_colsq / k_lz_update stride rows by workgroup
                 const double eps = sizeof(T) == 4 ? 1e-6 : 1e-14;
                 int nsq = npart_start;  // slabs of column sums of squares waiting in partial_sq
                 if (!(sub == 0 && start_colsq_ready)) {
@@ -283,7 +284,7 @@ template <typename T> struct ExpmEngine {
                 }
                 MMW_TRY(kbegin(KT_KRYLOV_VEC));
                 const bool last = sub + 1 == nsub;
-                hipLaunchKernelGGL((k_lz_combine<T>), dim3(nblk), dim3(BLOCK), 0, st, K, Dpad, m, U.p, bs, Tm.p, S.coef, out, pd,
+                hipLaunchKernelGGL((k_lz_combine<T>), dim3(nwide), dim3(BLOCK), 0, st, K, Dpad, m, U.p, bs, Tm.p, S.coef, out, pd,
                                    last ? rownorm_d : (T*)nullptr, last ? rownorm_part : (double*)nullptr);
                 MMW_TRY(kend());
             } else {

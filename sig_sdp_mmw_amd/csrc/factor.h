@@ -240,7 +240,7 @@ template <typename T> struct Factorizer {
         if (make_layout(b, V16<T>::N, lay, err) != MMW_OK) return fail(MMW_ERR_ARG, "mmw_factor: " + err);
         const int ld = lay.Dpad;
         const size_t bs = (size_t)K * ld;
-        const int nblk = grid_rows(K);
+        const int nblk = grid_slabs(K);
         if (V.n < bs) { MMW_TRY(V.alloc(bs)); MMW_TRY(W.alloc(bs)); MMW_TRY(Y1.alloc(bs)); MMW_TRY(Y2.alloc(bs)); }
         if (partial.n < (size_t)MAX_PART * ld) MMW_TRY(partial.alloc((size_t)MAX_PART * ld));
         if (colsum.n < (size_t)ld) MMW_TRY(colsum.alloc(ld));

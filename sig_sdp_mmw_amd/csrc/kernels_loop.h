@@ -122,7 +122,8 @@ __global__ __launch_bounds__(BLOCK) void k_softmax_a(PatternDev<T> P, const T* _
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_softmax_b(int C, T* __restrict__ Y, T* __restrict__ yavg, int accumulate,
                                                      const double* __restrict__ sum_part, int npart,
-                                                     double* __restrict__ scal /* [4] */) {
+                                                     double* __restrict__ scal /* [4] */, int baseH, const T* __restrict__ inv_norm_H,
+                                                     T* __restrict__ wH /* [K]: Y_H / norm_H, the weight the LOSS gathers */) {
     __shared__ double sh[WAVES_PER_BLOCK];
     double s[4];
     for (int q = 0; q < 4; ++q) {
@@ -135,6 +136,7 @@ __global__ __launch_bounds__(BLOCK) void k_softmax_b(int C, T* __restrict__ Y, T
         const T y = (T)((double)Y[c] / total);
         Y[c] = y;
         if (accumulate) yavg[c] += y;
+        if (c >= baseH) wH[c - baseH] = (T)((double)y * (double)inv_norm_H[c - baseH]);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         scal[0] = s[0] / total;
@@ -144,16 +146,22 @@ __global__ __launch_bounds__(BLOCK) void k_softmax_b(int C, T* __restrict__ Y, T
     }
 }
 
+// wH = Y_H / norm_H (the LOSS gathers it once per side of a gain edge); the loop gets it from softmax pass B
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_hweights(int K, const T* __restrict__ yH, const T* __restrict__ inv_norm_H, T* __restrict__ wH) {
+    for (int k = blockIdx.x * BLOCK + threadIdx.x; k < K; k += gridDim.x * BLOCK) wH[k] = (T)((double)yH[k] * (double)inv_norm_H[k]);
+}
+
 // ---- LOSS: lval -= eta * (LD + LF + LH) on the pattern; per-block partial of the diagonal sum ------
 // One thread per stored entry (row ids from `lrow`): every array is read fully coalesced, the only gathers
 // are the two dual weights of a gain edge.
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_loss(PatternDev<T> P, const int* __restrict__ lrow, const T* __restrict__ Y,
-                                                const double* __restrict__ scal, T* __restrict__ lval, double eta,
-                                                double* __restrict__ trace_part, const int* __restrict__ bpos,
+                                                const T* __restrict__ wH, const double* __restrict__ scal, T* __restrict__ lval,
+                                                double eta, double* __restrict__ trace_part, const int* __restrict__ bpos,
                                                 T* __restrict__ lval_blk) {
     __shared__ double sh[WAVES_PER_BLOCK];
-    const int K = P.K, Z = P.Z, baseF = K, baseH = K + P.E_asso;
+    const int K = P.K, Z = P.Z, baseF = K;
     const double invK = 1.0 / (double)K, Zm1 = (double)(Z - 1);
     const double cF = 0.5 + 1.0 / ((double)K * Zm1);
     const double sumYD = scal[0], sumYF = scal[1], sumW = scal[2];
@@ -168,8 +176,7 @@ __global__ __launch_bounds__(BLOCK) void k_loss(PatternDev<T> P, const int* __re
         } else if (P.pid[e] >= 0) {
             add = ((double)Y[baseF + P.pid[e]] * 0.5) / cF;
         } else {
-            const double w_row = (double)Y[baseH + row] * (double)P.inv_norm_H[row];
-            const double w_col = (double)Y[baseH + c] * (double)P.inv_norm_H[c];
+            const double w_row = (double)wH[row], w_col = (double)wH[c];  // one gather per side (softmax pass B made Y_H / norm_H)
             add = ((double)P.sab[e] * w_col + (double)P.sba[e] * w_row) * gscale;  // column-scaled S_T' symmetrised
         }
         const T nv = (T)((double)lval[e] - eta * add);

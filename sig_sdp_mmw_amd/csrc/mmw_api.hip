@@ -48,6 +48,8 @@ template <typename T> struct Solver final : mmw_solver {
     // iterate state
     DevBuf<T> lval, xval, xavg, Y, yavg, e_accu, e_this, rsum, Xh, drow;
     DevBuf<double> max_part, sum_part, scal, trace_part, tr_part, stage64, out64;
+    DevBuf<T> wH;  // Y_H / norm_H
+    static constexpr int LOSS_GRID_MAX = 4096;
     // locality blocking (blocking.h)
     HostBlocking HB;
     DevBuf<int> b_rowptr, b_order, b_unptr, b_uncols, b_bptr, b_bpos, b_bepos;
@@ -131,8 +133,8 @@ template <typename T> struct Solver final : mmw_solver {
         MMW_TRY(lval.alloc(nnz)); MMW_TRY(xval.alloc(nnz)); MMW_TRY(xavg.alloc(nnz));
         MMW_TRY(Y.alloc(C)); MMW_TRY(yavg.alloc(C)); MMW_TRY(e_accu.alloc(C)); MMW_TRY(e_this.alloc(C));
         MMW_TRY(rsum.alloc(K)); MMW_TRY(drow.alloc(K));
-        MMW_TRY(max_part.alloc(MAX_PART)); MMW_TRY(sum_part.alloc(4 * 2048)); MMW_TRY(scal.alloc(4));
-        MMW_TRY(trace_part.alloc(MAX_PART)); MMW_TRY(tr_part.alloc(MAX_PART));
+        MMW_TRY(max_part.alloc(ROW_GRID_MAX)); MMW_TRY(sum_part.alloc(4 * 2048)); MMW_TRY(scal.alloc(4));
+        MMW_TRY(trace_part.alloc(LOSS_GRID_MAX)); MMW_TRY(tr_part.alloc(ROW_GRID_MAX)); MMW_TRY(wH.alloc(K));
         MMW_TRY(eng.init(st, K, D, d_indptr.p, d_col.p, lval.p));
         kt.st = st;
         eng.kt = &kt;
@@ -436,7 +438,7 @@ template <typename T> struct Solver final : mmw_solver {
         const int gr = grid_rows(K);
         const int C = (int)H.C();
         const int gc = grid_elems((size_t)C);
-        const int gl = std::min(grid_elems((size_t)H.nnzL()), MAX_PART);  // LOSS: one thread per stored entry
+        const int gl = (int)std::min<size_t>(((size_t)H.nnzL() + BLOCK - 1) / BLOCK, (size_t)LOSS_GRID_MAX);  // LOSS: one thread per stored entry
         const int Dpad = eng.lay.Dpad;
         int m_launch = optimistic ? m_guess : 0;
         for (int it = 0; it < n; ++it) {
@@ -452,12 +454,12 @@ template <typename T> struct Solver final : mmw_solver {
             hipLaunchKernelGGL((k_dual_rows<T>), dim3(gr), dim3(BLOCK), 0, st, P, xval.p, rsum.p, e_this.p);
             hipLaunchKernelGGL((k_dual_h<T>), dim3(gr), dim3(BLOCK), 0, st, P, rsum.p, e_this.p, e_accu.p, eta, max_part.p);
             hipLaunchKernelGGL((k_softmax_a<T>), dim3(gc), dim3(BLOCK), 0, st, P, e_accu.p, Y.p, max_part.p, gr, sum_part.p);
-            hipLaunchKernelGGL((k_softmax_b<T>), dim3(gc), dim3(BLOCK), 0, st, C, Y.p, yavg.p, acc, sum_part.p, gc, scal.p);
+            hipLaunchKernelGGL((k_softmax_b<T>), dim3(gc), dim3(BLOCK), 0, st, C, Y.p, yavg.p, acc, sum_part.p, gc, scal.p, K + (int)H.E_asso(), d_invn.p, wH.p);
             MMW_TRY(kt.end());
             MMW_TRY(record(1));
             // ---- LOSS
             MMW_TRY(kt.begin(KT_LOSS));
-            hipLaunchKernelGGL((k_loss<T>), dim3(gl), dim3(BLOCK), 0, st, P, d_lrow.p, Y.p, scal.p, lval.p, eta, trace_part.p,
+            hipLaunchKernelGGL((k_loss<T>), dim3(gl), dim3(BLOCK), 0, st, P, d_lrow.p, Y.p, wH.p, scal.p, lval.p, eta, trace_part.p,
                                (const int*)(eng.use_blk ? b_bpos.p : nullptr), lval_blk.p);
             MMW_TRY(kt.end());
             MMW_TRY(record(2));

@@ -125,8 +125,9 @@ struct KernelTimers {
 inline int grid_rows(int rows) {  // one wavefront per row, 4 rows per workgroup, grid-stride beyond the cap
     int g = (rows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     if (g < 1) g = 1;
-    return g > MAX_PART ? MAX_PART : g;
+    return g > ROW_GRID_MAX ? ROW_GRID_MAX : g;  // short rows are latency chains: one row per wave beats grid-striding
 }
+inline int grid_slabs(int rows) { return std::min(grid_rows(rows), MAX_PART); }  // kernels that write a Dpad-wide slab per workgroup
 inline int grid_elems(size_t n) {
     size_t g = (n + BLOCK - 1) / BLOCK;
     if (g < 1) g = 1;
