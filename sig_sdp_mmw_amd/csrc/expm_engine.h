@@ -47,6 +47,41 @@ inline int spmm_launch(hipStream_t st, int K, const BlockLayout& lay, int nblk, 
     return MMW_OK;
 }
 
+// Static schedule of the half-tile SpMM.  Two workgroups are resident per CU and a workgroup is latency-bound (it takes
+// about the same time alone or paired), so the launch is cut into ~4 rounds of short workgroups: tile groups of
+// nb * ntiles / (4 * slots) tiles.  Short workgroups re-stage the block's entries once per tile group (fabric traffic
+// 79 MB vs 41 MB algorithmic at the bench config, all of it Infinity-Cache hits) but two co-resident workgroups in
+// different phases interleave better than two long ones in lockstep: whole blocks first and only the last partial
+// round cut into pieces (MMW_SCHED=2) moves 40 % fewer bytes and measures 5 % slower.
+inline Blk2Sched blk2_schedule(int nb, int ntiles) {
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        slots = 2 * (cus > 0 ? cus : 256);
+    }
+    Blk2Sched s;
+    static const bool two_phase = getenv("MMW_SCHED") && atoi(getenv("MMW_SCHED")) == 2;
+    if (!two_phase) {
+        int tpw = (int)((double)nb * ntiles / (4.0 * slots) + 0.5);
+        if (const char* e = getenv("MMW_TPW")) tpw = atoi(e);
+        tpw = tpw < 1 ? 1 : (tpw > ntiles ? ntiles : tpw);
+        s.nfull = 0; s.grid1 = 0; s.tpw_tail = tpw; s.groups_tail = (ntiles + tpw - 1) / tpw;
+        return s;
+    }
+    s.nfull = nb / slots * slots;
+    s.grid1 = (s.nfull + 7) / 8 * 8;
+    const int rem = nb - s.nfull;
+    s.tpw_tail = ntiles; s.groups_tail = 1;
+    double best = 1e300;
+    for (int g = 1; g <= ntiles && rem > 0; ++g) {  // rounds x (prologue + tiles), in units of one tile's time
+        const int tpw = (ntiles + g - 1) / g, groups = (ntiles + tpw - 1) / tpw;
+        const double cost = (double)((rem * groups + slots - 1) / slots) * (1.2 + tpw);
+        if (cost < best - 1e-9) { best = cost; s.tpw_tail = tpw; s.groups_tail = groups; }
+    }
+    return s;
+}
+
 inline unsigned long long* g_blk_stamps = nullptr;  // diagnostic builds only: per-workgroup phase stamps
 // one launch of the LDS-staged blocked SpMM (values in blocked order)
 template <typename T, int MODE>
@@ -55,18 +90,15 @@ inline int spmm_blk_launch(hipStream_t st, const BlkDev& B, int Dpad, const T* v
     if (B.half_tile) {
         constexpr int CT2 = B2_ROW_BYTES / (int)sizeof(T);
         const int ntiles = (Dpad + CT2 - 1) / CT2;
-        int tpw = (int)((double)B.nb * ntiles / (4.0 * 512.0) + 0.5);  // ~4 rounds of the 512 resident workgroups
-        if (getenv("MMW_TPW")) tpw = atoi(getenv("MMW_TPW"));
-        tpw = tpw < 1 ? 1 : (tpw > ntiles ? ntiles : tpw);
-        const int total = B.nb * ((ntiles + tpw - 1) / tpw);
-        const int per = (total + 7) / 8;
+        const Blk2Sched sched = blk2_schedule(B.nb, ntiles);
+        const int rem = B.nb - sched.nfull;
+        const int grid = sched.grid1 + ((rem * sched.groups_tail + 7) / 8) * 8;
         static bool attr2_set = false;  // per (T, MODE) instantiation
         if (!attr2_set) {
             MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_blk2<T, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS_BYTES));
             attr2_set = true;
         }
-        static const int late = getenv("MMW_LATE_GATHER") ? 0x100 : 0;
-        hipLaunchKernelGGL((k_spmm_blk2<T, MODE>), dim3(per * 8), dim3(B2_THREADS), B2_LDS_BYTES, st, B, Dpad, ntiles, tpw | late, val_blk, in, out, F, X2, c1, c2, c3, partial, plan, step, g_blk_stamps);
+        hipLaunchKernelGGL((k_spmm_blk2<T, MODE>), dim3(grid), dim3(B2_THREADS), B2_LDS_BYTES, st, B, Dpad, ntiles, sched, val_blk, in, out, F, X2, c1, c2, c3, partial, plan, step, g_blk_stamps);
         MMW_HIP(hipGetLastError());
         return MMW_OK;
     }

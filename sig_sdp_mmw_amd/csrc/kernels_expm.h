@@ -506,9 +506,15 @@ __device__ __forceinline__ void quad_bcast(const BlkMeta<double>& e, unsigned (&
     v[3] = __longlong_as_double((long long)(((unsigned long long)quad_lane<3>(hi) << 32) | quad_lane<3>(lo)));
 }
 
+struct Blk2Sched {
+    int nfull;        // row blocks [0, nfull) run whole (all tiles), one workgroup each
+    int grid1;        // nfull rounded up to 8 (the XCD interleave)
+    int tpw_tail;     // tiles per workgroup for the remaining blocks
+    int groups_tail;  // ceil(ntiles / tpw_tail)
+};
 template <typename T, int MODE>
 __global__ __launch_bounds__(B2_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void k_spmm_blk2(BlkDev B, int Dpad, int ntiles, int tpw, const T* __restrict__ val_blk, const T* __restrict__ U, T* __restrict__ Out,
+void k_spmm_blk2(BlkDev B, int Dpad, int ntiles, Blk2Sched sched, const T* __restrict__ val_blk, const T* __restrict__ U, T* __restrict__ Out,
                  T* __restrict__ F, const T* __restrict__ X2, double ascale, double shift, double inv_k, double* __restrict__ partial,
                  const ExpmPlan* __restrict__ plan, int step, unsigned long long* __restrict__ stamps) {
     constexpr int VEC = V16<T>::N;
@@ -523,21 +529,29 @@ void k_spmm_blk2(BlkDev B, int Dpad, int ntiles, int tpw, const T* __restrict__ 
         if (step > plan->m) return;
         if (MODE == SPMM_TAYLOR) shift = plan->mu / plan->nsub;
     }
-    const bool late_gather = (tpw & 0x100) != 0;
-    tpw &= 0xFF;
     constexpr int RPP = B2_THREADS / 8;        // union rows gathered per pass
     constexpr int NG = (BLK_UNION_ROWS + RPP - 1) / RPP;   // gathers per thread
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     int4* rowinfo = reinterpret_cast<int4*>(smem_raw);                          // [64]
     double* shdot = reinterpret_cast<double*>(smem_raw + 1024 + 1792);         // [B2_WAVES][CT]
     char* tile = smem_raw + B2_HEADER_BYTES;                                   // [max(nun,2)][128 B]
-    const int ngroups = (ntiles + tpw - 1) / tpw;
-    const int total = B.nb * ngroups;
-    const int per = (total + 7) / 8;
-    const int id = (blockIdx.x & 7) * per + (blockIdx.x >> 3);  // XCD-aware: one XCD walks consecutive row blocks
-    if (id >= total) return;
-    const int tg = id / B.nb, rb = id - tg * B.nb;
-    const int t0 = tg * tpw, t1 = min(ntiles, t0 + tpw);
+    // Two-phase static schedule (Blk2Sched): whole row blocks first, one workgroup each; the blocks that would start a
+    // mostly empty last round are cut into tile groups so that their pieces fill the chip.  Ids are XCD-aware within a phase.
+    int rb, t0, t1;
+    if ((int)blockIdx.x < sched.grid1) {
+        const int id = (blockIdx.x & 7) * (sched.grid1 >> 3) + (blockIdx.x >> 3);
+        if (id >= sched.nfull) return;
+        rb = id; t0 = 0; t1 = ntiles;
+    } else {
+        const int b2 = blockIdx.x - sched.grid1, rem = B.nb - sched.nfull;
+        const int total = rem * sched.groups_tail;
+        const int id = (b2 & 7) * ((total + 7) >> 3) + (b2 >> 3);
+        if (id >= total) return;
+        const int tg = id / rem;
+        rb = sched.nfull + id - tg * rem;
+        t0 = tg * sched.tpw_tail; t1 = min(ntiles, t0 + sched.tpw_tail);
+        if (t0 >= t1) return;
+    }
     const int* dsc = B.desc + (size_t)rb * 8;
     const int q0 = dsc[0], nrows = dsc[1];
     const int m0 = dsc[2], nmeta = dsc[3];
@@ -600,7 +614,7 @@ void k_spmm_blk2(BlkDev B, int Dpad, int ntiles, int tpw, const T* __restrict__ 
     __syncthreads();
     MMW_STAMP(4);
     for (int t = t0; t < t1; ++t) {
-        if (t + 1 < t1 && !late_gather) gather(t + 1);  // next tile's rows fly while this tile is consumed from LDS
+        if (t + 1 < t1) gather(t + 1);  // next tile's rows fly while this tile is consumed from LDS
         const int col0 = t * CT;
         const bool colok = col0 + l8 * VEC < Dpad;
         T dotw[VEC];  // alpha numerators of this wave's rows (lanes of group 0)
@@ -708,7 +722,6 @@ void k_spmm_blk2(BlkDev B, int Dpad, int ntiles, int tpw, const T* __restrict__ 
 #pragma unroll
             for (int v = 0; v < VEC; ++v) shdot[wib * CT + l8 * VEC + v] = (double)dotw[v];
         }
-        if (t + 1 < t1 && late_gather) gather(t + 1);
         if (t == t0) MMW_STAMP(5);
         __syncthreads();  // every wave is done with this tile (and shdot is complete)
         if (t == t0) MMW_STAMP(6);
