@@ -132,7 +132,7 @@ template <typename T> struct ExpmEngine {
     const T* val = nullptr;
     DevBuf<T> U;        // (max_order + 1) blocks of K*Dpad; block 0 is the start block
     DevBuf<T> Tm;       // A * U_j
-    DevBuf<double> partial, partial_sq, colsum, scal, rho_part, trace_own;  // partial: alpha numerators; partial_sq: column sums of squares
+    DevBuf<double> partial, partial_sq, colsum, scal, row_off, row_diag;  // partial: alpha numerators; partial_sq: column sums of squares
     DevBuf<ExpmPlan> plan_d;
     DevBuf<int> viol_d;
     ExpmPlan* plan_h = nullptr;  // pinned
@@ -176,8 +176,8 @@ template <typename T> struct ExpmEngine {
         npart = nblk;
         MMW_TRY(colsum.alloc(lay.Dpad));
         MMW_TRY(scal.alloc((size_t)4 * (MAX_ORDER + 2) * lay.Dpad));
-        MMW_TRY(rho_part.alloc(ROW_GRID_MAX));
-        MMW_TRY(trace_own.alloc(MAX_PART));
+        MMW_TRY(row_off.alloc(K));
+        MMW_TRY(row_diag.alloc(K));
         MMW_TRY(plan_d.alloc(1));
         MMW_TRY(viol_d.alloc(1));
         MMW_HIP(hipMemsetAsync(viol_d.p, 0, sizeof(int), st));
@@ -237,20 +237,13 @@ template <typename T> struct ExpmEngine {
         return MMW_OK;
     }
 
-    // plan from the current values; trace_part: per-block diagonal sums made by the producer (or null).
+    // plan from the current values.
     // m_launch == 0: read the plan back (one stream sync) and launch exactly what it asks for;
     // m_launch  > 0: no readback -- the caller launches m_launch single-substep stages and the kernels
     //                themselves skip the stages beyond the device-side order (viol is raised if it needs more).
-    int make_plan(double ascale, const double* trace_part, int ntrace, int m_launch) {
-        if (!trace_part) {
-            const int g = grid_elems((size_t)K);
-            hipLaunchKernelGGL((k_tracepart<T>), dim3(g), dim3(BLOCK), 0, st, K, indptr, col, val, trace_own.p);
-            trace_part = trace_own.p;
-            ntrace = g;
-        }
-        hipLaunchKernelGGL((k_rowabs<T>), dim3(nwide), dim3(BLOCK), 0, st, K, indptr, col, val, ascale, trace_part, ntrace, rho_part.p);
-        hipLaunchKernelGGL(k_plan, dim3(1), dim3(BLOCK), 0, st, K, method, max_order, tol, ascale, rho_part.p, nwide, trace_part, ntrace, plan_d.p,
-                           m_launch, viol_d.p);
+    int make_plan(double ascale, int m_launch) {
+        hipLaunchKernelGGL((k_rowsums<T>), dim3(nwide), dim3(BLOCK), 0, st, K, indptr, col, val, ascale, row_off.p, row_diag.p);
+        hipLaunchKernelGGL(k_plan, dim3(1), dim3(PLAN_THREADS), 0, st, K, method, max_order, tol, row_off.p, row_diag.p, plan_d.p, m_launch, viol_d.p);
         MMW_HIP(hipGetLastError());
         if (m_launch > 0) return MMW_OK;
         MMW_HIP(hipMemcpyAsync(plan_h, plan_d.p, sizeof(ExpmPlan), hipMemcpyDeviceToHost, st));
@@ -275,8 +268,8 @@ template <typename T> struct ExpmEngine {
     }
 
     // out = exp(ascale*A) * start_block().  `out` must not alias the engine's blocks.
-    int apply(T* out, double ascale, const double* trace_part = nullptr, int ntrace = 0, int m_launch = 0) {
-        MMW_TRY(make_plan(ascale, trace_part, ntrace, m_launch));
+    int apply(T* out, double ascale, int m_launch = 0) {
+        MMW_TRY(make_plan(ascale, m_launch));
         const int m = m_launch > 0 ? m_launch : last.m;
         const int nsub = m_launch > 0 ? 1 : last.nsub;
         MMW_TRY(ensure_blocks(std::max(3, m)));

@@ -1123,17 +1123,27 @@ __global__ __launch_bounds__(BLOCK) void k_rowabs(int K, const int* __restrict__
     best = block_max(best, sh);
     if (threadIdx.x == 0) partial[blockIdx.x] = best;
 }
-// diagonal sums when no producer kernel made them (stand-alone expm)
+// per row: off[row] = sum_{col != row} |ascale*val|, diag[row] = ascale*val[row,row].  One wave per row; the shift mu and
+// the 1-norm bound max_i(|diag_i - mu| + off_i) are formed by k_plan (one workgroup), so no kernel re-reduces a slab.
 template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_tracepart(int K, const int* __restrict__ indptr, const int* __restrict__ col,
-                                                     const T* __restrict__ val, double* __restrict__ partial) {
-    __shared__ double sh[WAVES_PER_BLOCK];
-    double s = 0.0;
-    for (int row = blockIdx.x * BLOCK + threadIdx.x; row < K; row += gridDim.x * BLOCK)
-        for (int e = indptr[row]; e < indptr[row + 1]; ++e)
-            if (col[e] == row) s += (double)val[e];
-    s = block_sum(s, sh);
-    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+__global__ __launch_bounds__(BLOCK) void k_rowsums(int K, const int* __restrict__ indptr, const int* __restrict__ col,
+                                                   const T* __restrict__ val, double ascale, double* __restrict__ off,
+                                                   double* __restrict__ diag) {
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    for (int row = blockIdx.x * WAVES_PER_BLOCK + wib; row < K; row += gridDim.x * WAVES_PER_BLOCK) {
+        double s = 0.0, d = 0.0;
+        for (int e = indptr[row] + lane; e < indptr[row + 1]; e += WAVE) {
+            const double v = ascale * (double)val[e];
+            if (col[e] == row) d = v;
+            else s += fabs(v);
+        }
+        s = wave_sum(s);
+        d = wave_sum(d);  // exactly one lane holds the diagonal
+        if (lane == 0) {
+            off[row] = s;
+            diag[row] = d;
+        }
+    }
 }
 
 __host__ __device__ inline int plan_order(int method, double rho, double tol, int max_order) {
@@ -1156,19 +1166,25 @@ __host__ __device__ inline int plan_order(int method, double rho, double tol, in
 
 // m_launch > 0: the host has already decided to launch m_launch steps with a single substep (no readback);
 // if the matrix needs more, the sticky flag *viol is raised and the caller replays the batch synchronously.
-__global__ void k_plan(int K, int method, int max_order, double tol, double ascale, const double* __restrict__ rho_part, int nrho,
-                       const double* __restrict__ trace_part, int ntrace, ExpmPlan* __restrict__ plan, int m_launch,
-                       int* __restrict__ viol) {
-    __shared__ double sh[WAVES_PER_BLOCK];
-    double r = 0.0, tr = 0.0;
-    for (int i = threadIdx.x; i < nrho; i += blockDim.x) r = rho_part[i] > r ? rho_part[i] : r;
-    for (int i = threadIdx.x; i < ntrace; i += blockDim.x) tr += trace_part[i];
-    r = block_max(r, sh);
+constexpr int PLAN_THREADS = 1024;
+__global__ __launch_bounds__(PLAN_THREADS) void k_plan(int K, int method, int max_order, double tol, const double* __restrict__ off,
+                                                       const double* __restrict__ diag, ExpmPlan* __restrict__ plan, int m_launch,
+                                                       int* __restrict__ viol) {
+    __shared__ double sh[PLAN_THREADS / WAVE];
+    double tr = 0.0;
+    for (int i = threadIdx.x; i < K; i += PLAN_THREADS) tr += diag[i];  // diag already carries ascale
     tr = block_sum(tr, sh);
+    const double mu = tr / K;
+    double r = 0.0;
+    for (int i = threadIdx.x; i < K; i += PLAN_THREADS) {
+        const double b = fabs(diag[i] - mu) + off[i];
+        r = b > r ? b : r;
+    }
+    r = block_max(r, sh);
     if (threadIdx.x == 0) {
         ExpmPlan p;
         p.rho = r;
-        p.mu = ascale * tr / K;
+        p.mu = mu;
         p.overflow = 0;
         p.pad = 0;
         int nsub = 1, m = -1;

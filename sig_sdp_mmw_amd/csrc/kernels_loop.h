@@ -152,22 +152,19 @@ __global__ __launch_bounds__(BLOCK) void k_hweights(int K, const T* __restrict__
     for (int k = blockIdx.x * BLOCK + threadIdx.x; k < K; k += gridDim.x * BLOCK) wH[k] = (T)((double)yH[k] * (double)inv_norm_H[k]);
 }
 
-// ---- LOSS: lval -= eta * (LD + LF + LH) on the pattern; per-block partial of the diagonal sum ------
+// ---- LOSS: lval -= eta * (LD + LF + LH) on the pattern ----------------------------------------------
 // One thread per stored entry (row ids from `lrow`): every array is read fully coalesced, the only gathers
 // are the two dual weights of a gain edge.
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_loss(PatternDev<T> P, const int* __restrict__ lrow, const T* __restrict__ Y,
                                                 const T* __restrict__ wH, const double* __restrict__ scal, T* __restrict__ lval,
-                                                double eta, double* __restrict__ trace_part, const int* __restrict__ bpos,
-                                                T* __restrict__ lval_blk) {
-    __shared__ double sh[WAVES_PER_BLOCK];
+                                                double eta, const int* __restrict__ bpos, T* __restrict__ lval_blk) {
     const int K = P.K, Z = P.Z, baseF = K;
     const double invK = 1.0 / (double)K, Zm1 = (double)(Z - 1);
     const double cF = 0.5 + 1.0 / ((double)K * Zm1);
     const double sumYD = scal[0], sumYF = scal[1], sumW = scal[2];
     const double dconst = -(sumYD * invK) / (1.0 - invK) + (sumYF / ((double)K * Zm1)) / cF - sumW;
     const double gscale = Zm1 / (double)(2 * Z);
-    double tr = 0.0;
     for (int e = blockIdx.x * BLOCK + threadIdx.x; e < P.nnzL; e += gridDim.x * BLOCK) {
         const int row = lrow[e], c = P.col[e];
         double add;
@@ -182,10 +179,7 @@ __global__ __launch_bounds__(BLOCK) void k_loss(PatternDev<T> P, const int* __re
         const T nv = (T)((double)lval[e] - eta * add);
         lval[e] = nv;
         if (bpos) lval_blk[bpos[e]] = nv;  // the same value in the LDS-staged kernel's traversal order
-        if (c == row) tr += (double)nv;
     }
-    tr = block_sum(tr, sh);
-    if (threadIdx.x == 0) trace_part[blockIdx.x] = tr;
 }
 
 // ---- row norms of X_half: d[row] = ||y_row||^2, per-block partial sums of d -----------------------

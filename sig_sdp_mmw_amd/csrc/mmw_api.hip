@@ -47,7 +47,7 @@ template <typename T> struct Solver final : mmw_solver {
     DevBuf<T> d_sab, d_sba, d_h, d_ssum, d_invn, d_cH;
     // iterate state
     DevBuf<T> lval, xval, xavg, Y, yavg, e_accu, e_this, rsum, Xh, drow;
-    DevBuf<double> max_part, sum_part, scal, trace_part, tr_part, stage64, out64;
+    DevBuf<double> max_part, sum_part, scal, tr_part, stage64, out64;
     DevBuf<T> wH;  // Y_H / norm_H
     static constexpr int LOSS_GRID_MAX = 4096;
     // locality blocking (blocking.h)
@@ -134,7 +134,7 @@ template <typename T> struct Solver final : mmw_solver {
         MMW_TRY(Y.alloc(C)); MMW_TRY(yavg.alloc(C)); MMW_TRY(e_accu.alloc(C)); MMW_TRY(e_this.alloc(C));
         MMW_TRY(rsum.alloc(K)); MMW_TRY(drow.alloc(K));
         MMW_TRY(max_part.alloc(ROW_GRID_MAX)); MMW_TRY(sum_part.alloc(4 * 2048)); MMW_TRY(scal.alloc(4));
-        MMW_TRY(trace_part.alloc(LOSS_GRID_MAX)); MMW_TRY(tr_part.alloc(ROW_GRID_MAX)); MMW_TRY(wH.alloc(K));
+        MMW_TRY(tr_part.alloc(ROW_GRID_MAX)); MMW_TRY(wH.alloc(K));
         MMW_TRY(eng.init(st, K, D, d_indptr.p, d_col.p, lval.p));
         kt.st = st;
         eng.kt = &kt;
@@ -459,7 +459,7 @@ template <typename T> struct Solver final : mmw_solver {
             MMW_TRY(record(1));
             // ---- LOSS
             MMW_TRY(kt.begin(KT_LOSS));
-            hipLaunchKernelGGL((k_loss<T>), dim3(gl), dim3(BLOCK), 0, st, P, d_lrow.p, Y.p, wH.p, scal.p, lval.p, eta, trace_part.p,
+            hipLaunchKernelGGL((k_loss<T>), dim3(gl), dim3(BLOCK), 0, st, P, d_lrow.p, Y.p, wH.p, scal.p, lval.p, eta,
                                (const int*)(eng.use_blk ? b_bpos.p : nullptr), lval_blk.p);
             MMW_TRY(kt.end());
             MMW_TRY(record(2));
@@ -480,7 +480,7 @@ template <typename T> struct Solver final : mmw_solver {
             MMW_HIP(hipGetLastError());
             eng.rownorm_d = drow.p;  // the Lanczos combination also emits the row norms and the trace slabs
             eng.rownorm_part = tr_part.p;
-            MMW_TRY(eng.apply(Xh.p, 0.5, trace_part.p, gl, m_launch));
+            MMW_TRY(eng.apply(Xh.p, 0.5, m_launch));
             MMW_TRY(kt.begin(KT_SDDMM));
             if (eng.method != MMW_EXPM_LANCZOS)
                 hipLaunchKernelGGL((k_rownorm2<T>), dim3(gr), dim3(BLOCK), 0, st, K, Dpad, Xh.p, drow.p, tr_part.p);

@@ -20,7 +20,7 @@ template <typename T> struct Extras {
     Factorizer<T> fac;
     // gap work
     DevBuf<T> g_x, g_l, g_y, g_e1, g_e2, g_r, g_vec, g_tm;
-    DevBuf<double> g_part, g_scal, g_lz, g_colsum, g_trace;
+    DevBuf<double> g_part, g_scal, g_lz, g_colsum;
 
     int init(hipStream_t s, const HostPattern* h, int K_, KernelTimers* k) {
         st = s; H = h; K = K_; kt = k;
@@ -43,7 +43,7 @@ template <typename T> struct Extras {
         const size_t nnz = (size_t)P.nnzL, C = (size_t)P.C;
         const int gr = grid_rows(K);
         MMW_TRY(ensure(g_x, nnz)); MMW_TRY(ensure(g_l, nnz)); MMW_TRY(ensure(g_y, C)); MMW_TRY(ensure(g_e1, C)); MMW_TRY(ensure(g_e2, C));
-        MMW_TRY(ensure(g_r, K)); MMW_TRY(ensure(g_part, ROW_GRID_MAX)); MMW_TRY(ensure(g_scal, 8)); MMW_TRY(ensure(g_trace, ROW_GRID_MAX));
+        MMW_TRY(ensure(g_r, K)); MMW_TRY(ensure(g_part, ROW_GRID_MAX)); MMW_TRY(ensure(g_scal, 8));
         const double inv = 1.0 / (double)nterms;
         hipLaunchKernelGGL((k_scaled_copy<T>), dim3(grid_elems(nnz)), dim3(BLOCK), 0, st, nnz, xavg, inv, g_x.p);
         hipLaunchKernelGGL((k_scaled_copy<T>), dim3(grid_elems(C)), dim3(BLOCK), 0, st, C, yavg, inv, g_y.p);
@@ -56,7 +56,7 @@ template <typename T> struct Extras {
         hipLaunchKernelGGL((k_ysums<T>), dim3(1), dim3(BLOCK), 0, st, K, P.E_asso, g_y.p, P.cH, P.inv_norm_H, g_scal.p);
         MMW_HIP(hipMemsetAsync(g_l.p, 0, nnz * sizeof(T), st));
         hipLaunchKernelGGL((k_hweights<T>), dim3(grid_elems((size_t)K)), dim3(BLOCK), 0, st, K, g_y.p + (K + P.E_asso), P.inv_norm_H, g_r.p);  // g_r is free again
-        hipLaunchKernelGGL((k_loss<T>), dim3(gr), dim3(BLOCK), 0, st, P, lrow, g_y.p, g_r.p, g_scal.p, g_l.p, -1.0, g_trace.p, (const int*)nullptr, (T*)nullptr);
+        hipLaunchKernelGGL((k_loss<T>), dim3(gr), dim3(BLOCK), 0, st, P, lrow, g_y.p, g_r.p, g_scal.p, g_l.p, -1.0, (const int*)nullptr, (T*)nullptr);
         MMW_HIP(hipGetLastError());
         double emax = 0.0;
         MMW_HIP(hipMemcpyAsync(&emax, g_scal.p + 4, sizeof(double), hipMemcpyDeviceToHost, st));
