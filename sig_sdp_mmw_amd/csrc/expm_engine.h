@@ -132,7 +132,7 @@ template <typename T> struct ExpmEngine {
     const T* val = nullptr;
     DevBuf<T> U;        // (max_order + 1) blocks of K*Dpad; block 0 is the start block
     DevBuf<T> Tm;       // A * U_j
-    DevBuf<double> partial, partial_sq, colsum, scal, row_off, row_diag;  // partial: alpha numerators; partial_sq: column sums of squares
+    DevBuf<double> partial, partial_sq, colsum, scal, row_part;  // partial: alpha numerators; partial_sq: column sums of squares
     DevBuf<ExpmPlan> plan_d;
     DevBuf<int> viol_d;
     ExpmPlan* plan_h = nullptr;  // pinned
@@ -176,8 +176,7 @@ template <typename T> struct ExpmEngine {
         npart = nblk;
         MMW_TRY(colsum.alloc(lay.Dpad));
         MMW_TRY(scal.alloc((size_t)4 * (MAX_ORDER + 2) * lay.Dpad));
-        MMW_TRY(row_off.alloc(K));
-        MMW_TRY(row_diag.alloc(K));
+        MMW_TRY(row_part.alloc((size_t)3 * ROW_GRID_MAX));
         MMW_TRY(plan_d.alloc(1));
         MMW_TRY(viol_d.alloc(1));
         MMW_HIP(hipMemsetAsync(viol_d.p, 0, sizeof(int), st));
@@ -242,8 +241,8 @@ template <typename T> struct ExpmEngine {
     // m_launch  > 0: no readback -- the caller launches m_launch single-substep stages and the kernels
     //                themselves skip the stages beyond the device-side order (viol is raised if it needs more).
     int make_plan(double ascale, int m_launch) {
-        hipLaunchKernelGGL((k_rowsums<T>), dim3(nwide), dim3(BLOCK), 0, st, K, indptr, col, val, ascale, row_off.p, row_diag.p);
-        hipLaunchKernelGGL(k_plan, dim3(1), dim3(PLAN_THREADS), 0, st, K, method, max_order, tol, row_off.p, row_diag.p, plan_d.p, m_launch, viol_d.p);
+        hipLaunchKernelGGL((k_rowsums<T>), dim3(nwide), dim3(BLOCK), 0, st, K, indptr, col, val, ascale, row_part.p);
+        hipLaunchKernelGGL(k_plan, dim3(1), dim3(PLAN_THREADS), 0, st, K, method, max_order, tol, row_part.p, nwide, plan_d.p, m_launch, viol_d.p);
         MMW_HIP(hipGetLastError());
         if (m_launch > 0) return MMW_OK;
         MMW_HIP(hipMemcpyAsync(plan_h, plan_d.p, sizeof(ExpmPlan), hipMemcpyDeviceToHost, st));

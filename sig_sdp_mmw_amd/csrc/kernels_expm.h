@@ -1123,13 +1123,16 @@ __global__ __launch_bounds__(BLOCK) void k_rowabs(int K, const int* __restrict__
     best = block_max(best, sh);
     if (threadIdx.x == 0) partial[blockIdx.x] = best;
 }
-// per row: off[row] = sum_{col != row} |ascale*val|, diag[row] = ascale*val[row,row].  One wave per row; the shift mu and
-// the 1-norm bound max_i(|diag_i - mu| + off_i) are formed by k_plan (one workgroup), so no kernel re-reduces a slab.
+// Per workgroup (4 rows, one wave each): {sum d_i, max(d_i + o_i), max(o_i - d_i)} with d_i = ascale*val[i,i] and
+// o_i = sum_{j != i} |ascale*val[i,j]|.  Since |x| = max(x, -x), the 1-norm bound of A - mu I is
+// max_i(|d_i - mu| + o_i) = max(max_i(d_i + o_i) - mu, max_i(o_i - d_i) + mu): k_plan gets mu = tr/K and the bound from
+// these three slabs in one short pass, and no kernel has to re-reduce a slab to know mu first.
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_rowsums(int K, const int* __restrict__ indptr, const int* __restrict__ col,
-                                                   const T* __restrict__ val, double ascale, double* __restrict__ off,
-                                                   double* __restrict__ diag) {
+                                                   const T* __restrict__ val, double ascale, double* __restrict__ part /* [3][grid] */) {
+    __shared__ double sh[WAVES_PER_BLOCK];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    double sd = 0.0, pp = -1e300, pm = -1e300;
     for (int row = blockIdx.x * WAVES_PER_BLOCK + wib; row < K; row += gridDim.x * WAVES_PER_BLOCK) {
         double s = 0.0, d = 0.0;
         for (int e = indptr[row] + lane; e < indptr[row + 1]; e += WAVE) {
@@ -1140,9 +1143,18 @@ __global__ __launch_bounds__(BLOCK) void k_rowsums(int K, const int* __restrict_
         s = wave_sum(s);
         d = wave_sum(d);  // exactly one lane holds the diagonal
         if (lane == 0) {
-            off[row] = s;
-            diag[row] = d;
+            sd += d;
+            pp = d + s > pp ? d + s : pp;
+            pm = s - d > pm ? s - d : pm;
         }
+    }
+    sd = block_sum(sd, sh);
+    pp = block_max(pp, sh);
+    pm = block_max(pm, sh);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = sd;
+        part[gridDim.x + blockIdx.x] = pp;
+        part[2 * gridDim.x + blockIdx.x] = pm;
     }
 }
 
@@ -1166,21 +1178,21 @@ __host__ __device__ inline int plan_order(int method, double rho, double tol, in
 
 // m_launch > 0: the host has already decided to launch m_launch steps with a single substep (no readback);
 // if the matrix needs more, the sticky flag *viol is raised and the caller replays the batch synchronously.
-constexpr int PLAN_THREADS = 1024;
-__global__ __launch_bounds__(PLAN_THREADS) void k_plan(int K, int method, int max_order, double tol, const double* __restrict__ off,
-                                                       const double* __restrict__ diag, ExpmPlan* __restrict__ plan, int m_launch,
-                                                       int* __restrict__ viol) {
+constexpr int PLAN_THREADS = 256;
+__global__ __launch_bounds__(PLAN_THREADS) void k_plan(int K, int method, int max_order, double tol, const double* __restrict__ part, int np,
+                                                       ExpmPlan* __restrict__ plan, int m_launch, int* __restrict__ viol) {
     __shared__ double sh[PLAN_THREADS / WAVE];
-    double tr = 0.0;
-    for (int i = threadIdx.x; i < K; i += PLAN_THREADS) tr += diag[i];  // diag already carries ascale
-    tr = block_sum(tr, sh);
-    const double mu = tr / K;
-    double r = 0.0;
-    for (int i = threadIdx.x; i < K; i += PLAN_THREADS) {
-        const double b = fabs(diag[i] - mu) + off[i];
-        r = b > r ? b : r;
+    double tr = 0.0, pp = -1e300, pm = -1e300;
+    for (int i = threadIdx.x; i < np; i += PLAN_THREADS) {
+        tr += part[i];
+        pp = part[np + i] > pp ? part[np + i] : pp;
+        pm = part[2 * np + i] > pm ? part[2 * np + i] : pm;
     }
-    r = block_max(r, sh);
+    tr = block_sum(tr, sh);
+    pp = block_max(pp, sh);
+    pm = block_max(pm, sh);
+    const double mu = tr / K;
+    const double r = pp - mu > pm + mu ? pp - mu : pm + mu;
     if (threadIdx.x == 0) {
         ExpmPlan p;
         p.rho = r;
