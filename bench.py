@@ -163,7 +163,7 @@ def main():
             except Exception:
                 pass
     blocked = bool(solver.read(_lib.F_BLOCKING)[0])
-    kname = ("k_spmm_blk (LDS-staged locality-blocked CSR SpMM" if blocked else "k_spmm (generic CSR gather SpMM") + " of the %s step)" % args.expm
+    kname = ("k_spmm_blk2 (LDS-staged locality-blocked CSR SpMM, 128-byte half tiles" if blocked else "k_spmm (generic CSR gather SpMM") + " of the %s step)" % args.expm
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "bytes_per_launch": int(b_spmm), "avg_launch_us": round(spmm_avg_us, 2), "launches": int(spmm_n),
