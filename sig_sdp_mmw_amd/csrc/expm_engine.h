@@ -18,6 +18,7 @@ inline int make_layout(int D, int vec, BlockLayout& lay, std::string& err) {
         lay.G = WAVE / lpr;
         lay.NCH = 1;
     } else {
+        lpr = (lpr + 7) / 8 * 8;  // rows in whole 128-byte cache lines: a gathered 128-byte piece then is ONE line, not two halves
         lay.G = 1;
         lay.NCH = (lpr + WAVE - 1) / WAVE;
         if (lay.NCH > 4) {

@@ -460,6 +460,8 @@ struct Sd2Dev {
     const int* ptr;            // [nb+1] slot ranges
     const unsigned* ab;        // la | lb << 16
     const int* epos;           // -1 idle
+    const int* items;          // [nitems][3] {row block, first round, end round}
+    int nitems;
 };
 constexpr int SD2_ROUNDS = 5;
 template <typename T>
@@ -486,9 +488,11 @@ void k_sddmm_blk2(BlkDev B, Sd2Dev S, PatternDev<T> P, int Dpad, int ntiles,
     for (int i = threadIdx.x; i < ntr; i += SD2_THREADS) tsum += tr_part[i];
     tsum = block_sum(tsum, sh);
     const double tr = tsum / (double)P.K;
-    const int per = (B.nb + 7) / 8;
-    const int rb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (rb >= B.nb) return;
+    // work items (row block, first round, end round), longest first; XCD-aware: consecutive items share an XCD's L2
+    const int per = (S.nitems + 7) / 8;
+    const int item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (item >= S.nitems) return;
+    const int rb = S.items[3 * item], k0 = S.items[3 * item + 1], k1 = S.items[3 * item + 2];
     const int l8 = threadIdx.x & 7, u0 = threadIdx.x >> 3;
     const int nun8 = (B.desc[(size_t)rb * 8 + 5] + 7) & ~7;
     unsigned gbase[NG];
@@ -522,7 +526,7 @@ void k_sddmm_blk2(BlkDev B, Sd2Dev S, PatternDev<T> P, int Dpad, int ntiles,
     };
     MMW_STAMP(1);
     gather(0);
-    const int s0 = S.ptr[rb], rounds = (S.ptr[rb + 1] - s0) / SD2_THREADS;
+    const int s0 = S.ptr[rb] + k0 * SD2_THREADS, rounds = k1 - k0;
     unsigned ab[SD2_ROUNDS];  // staged row indices of the entry's two rows, packed (registers are the budget here)
     int ep[SD2_ROUNDS];
     T acc[SD2_ROUNDS];
@@ -544,6 +548,7 @@ void k_sddmm_blk2(BlkDev B, Sd2Dev S, PatternDev<T> P, int Dpad, int ntiles,
     const int skew = threadIdx.x & 7;
     for (int t = 0; t < ntiles; ++t) {
         if (t + 1 < ntiles) gather(t + 1);
+        if (t == 0) MMW_STAMP(12);
 #pragma unroll
         for (int k = 0; k < SD2_ROUNDS; ++k) {
             if (k < rounds && ep[k] >= 0) {
@@ -583,7 +588,7 @@ void k_sddmm_blk2(BlkDev B, Sd2Dev S, PatternDev<T> P, int Dpad, int ntiles,
                 xavg[me] += xv;
             }
         }
-    const int q0 = B.rowptr[rb], q1 = B.rowptr[rb + 1];
+    const int q0 = B.rowptr[rb], q1 = k0 == 0 ? B.rowptr[rb + 1] : B.rowptr[rb];  // the item with the first round writes the diagonal
     for (int q = q0 + threadIdx.x; q < q1; q += SD2_THREADS) {
         const int row = B.order[q];
         const int dp = P.diag_pos[row];

@@ -2,6 +2,7 @@
 #include <chrono>
 #include <cstring>
 #include <map>
+#include <queue>
 #include <memory>
 
 #include "blocking.h"
@@ -56,7 +57,8 @@ template <typename T> struct Solver final : mmw_solver {
     DevBuf<unsigned short> b_lidx, b_selfli, b_sdla, b_sdlb;
     DevBuf<int> b_sdptr, b_sdepos, b_desc, b_unfixed;
     bool sddmm_blk = false;
-    DevBuf<int> b_sd2ptr, b_sd2epos;
+    DevBuf<int> b_sd2ptr, b_sd2epos, b_sd2items;
+    int sd2_nitems = 0;
     DevBuf<unsigned> b_sd2ab;
     bool sddmm_blk2 = false;  // half-tile SDDMM (k_sddmm_blk2)
     DevBuf<T> lval_blk;
@@ -183,6 +185,33 @@ template <typename T> struct Solver final : mmw_solver {
         }
         if (HB.sd2_rounds <= SD2_ROUNDS && (double)K * eng.lay.Dpad * sizeof(T) < 4.0e9 && !getenv("MMW_FULL_TILE")) {
             MMW_TRY(b_sd2ptr.upload(HB.sd2_ptr, st)); MMW_TRY(b_sd2ab.upload(HB.sd2_ab, st)); MMW_TRY(b_sd2epos.upload(HB.sd2_epos, st));
+            {   // Work items.  A workgroup is a latency chain whose length is its number of rounds, and the launch lasts as long
+                // as its longest workgroup; the resident slots the row blocks leave free are used to cut the longest items in two
+                // (each half stages the union again).
+                int cus = 256;
+                (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+                const int per_cu = std::max(1, std::min(3, 163840 / std::max(1, HB.un8_max * B2_ROW_BYTES + 128)));
+                const size_t slots = (size_t)per_cu * (size_t)cus;
+                struct It { int rb, k0, k1; };
+                auto len = [](const It& a) { return a.k1 - a.k0; };
+                auto less = [&](const It& a, const It& b) { return len(a) != len(b) ? len(a) < len(b) : a.rb > b.rb; };
+                std::priority_queue<It, std::vector<It>, decltype(less)> pq(less);
+                for (int b = 0; b < HB.nb(); ++b) pq.push({b, 0, (HB.sd2_ptr[b + 1] - HB.sd2_ptr[b]) / SD2_THREADS});
+                while (pq.size() < slots && len(pq.top()) >= 2) {
+                    const It t = pq.top();
+                    pq.pop();
+                    const int mid = t.k0 + (len(t) + 1) / 2;
+                    pq.push({t.rb, t.k0, mid});
+                    pq.push({t.rb, mid, t.k1});
+                }
+                std::vector<int32_t> items;
+                while (!pq.empty()) {  // longest first
+                    items.push_back(pq.top().rb); items.push_back(pq.top().k0); items.push_back(pq.top().k1);
+                    pq.pop();
+                }
+                sd2_nitems = (int)(items.size() / 3);
+                MMW_TRY(b_sd2items.upload(items, st));
+            }
             MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sddmm_blk2<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         HB.un8_max * B2_ROW_BYTES));
             sddmm_blk2 = true;
@@ -227,6 +256,14 @@ template <typename T> struct Solver final : mmw_solver {
             }
             fprintf(stderr, "[stamps] %d workgroups, span %.1f us; mean us per phase:", cnt, (double)(tmax - tmin) * 0.01);
             for (int k = 1; k < 10; ++k) fprintf(stderr, " p%d=%.2f", k, acc[k] / std::max(cnt, 1) * 0.01);
+            {
+                double g = 0; int c = 0;
+                for (int w = 0; w < 8192; ++w) {
+                    const unsigned long long* q = &h[(size_t)w * 16];
+                    if (q[4] && q[12]) { g += (double)(q[12] - q[4]); ++c; }
+                }
+                if (c) fprintf(stderr, " gather-issue(p5 part)=%.2f", g / c * 0.01);
+            }
             fprintf(stderr, "\n");
             // residency: workgroups whose [start, end) intervals overlap on the same (XCC, SE, SH, CU)
             std::map<unsigned long long, std::vector<std::pair<unsigned long long, int>>> ev;
@@ -249,6 +286,17 @@ template <typename T> struct Solver final : mmw_solver {
                     const double dt = (double)(v[i + 1].first - v[i].first);
                     if (live == 1) t1 += dt; else if (live == 2) t2 += dt; else if (live >= 3) t3 += dt;
                 }
+            }
+            {
+                std::vector<double> dur;
+                for (int w = 0; w < 8192; ++w) {
+                    const unsigned long long* q = &h[(size_t)w * 16];
+                    if (q[0] && q[9]) dur.push_back((double)(q[9] - q[0]) * 0.01);
+                }
+                std::sort(dur.begin(), dur.end());
+                if (!dur.empty())
+                    fprintf(stderr, "[stamps] workgroup us: min %.1f p25 %.1f p50 %.1f p75 %.1f p95 %.1f max %.1f\n", dur.front(), dur[dur.size() / 4],
+                            dur[dur.size() / 2], dur[dur.size() * 3 / 4], dur[dur.size() * 95 / 100], dur.back());
             }
             if (!ev.empty())
                 fprintf(stderr, "[stamps] %zu distinct CUs; mean workgroup %.2f us; per CU: %.1f us with 1 resident, %.1f us with 2, %.1f us with 3+\n", ev.size(),
@@ -493,9 +541,9 @@ template <typename T> struct Solver final : mmw_solver {
                     sd_stamps = stamp_buf.p;
                 }
                 Sd2Dev S;
-                S.ptr = b_sd2ptr.p; S.ab = b_sd2ab.p; S.epos = b_sd2epos.p;
+                S.ptr = b_sd2ptr.p; S.ab = b_sd2ab.p; S.epos = b_sd2epos.p; S.items = b_sd2items.p; S.nitems = sd2_nitems;
                 constexpr int CT2 = B2_ROW_BYTES / (int)sizeof(T);
-                const int per = (HB.nb() + 7) / 8;
+                const int per = (sd2_nitems + 7) / 8;
                 hipLaunchKernelGGL((k_sddmm_blk2<T>), dim3(per * 8), dim3(SD2_THREADS), (size_t)HB.un8_max * B2_ROW_BYTES, st, blkdev(), S, P, Dpad,
                                    (Dpad + CT2 - 1) / CT2, Xh.p, drow.p, tr_part.p, gr, xval.p, xavg.p, acc, sd_stamps);
                 if (sd_stamps) MMW_TRY(dump_stamps(sd_stamps));
