@@ -136,10 +136,19 @@ inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& i
             return;
     for (int k = 0; k < K; ++k)
         if (indptr[k + 1] - indptr[k] > BLK_UNION) return;  // a single row overflows the tile: generic kernel
-    B.order = rcm_order(K, indptr, indices);
+    const std::vector<int32_t> rcm = rcm_order(K, indptr, indices);
     std::vector<int32_t> rank(K);
-    for (int p = 0; p < K; ++p) rank[B.order[p]] = p;
-    // greedy row blocks over the RCM order
+    for (int p = 0; p < K; ++p) rank[rcm[p]] = p;
+    // Row blocks.  Seeds sweep the RCM order; a block then GROWS from its seed: the next row is the unassigned member of the
+    // union that brings the fewest new columns (ties: lowest RCM rank).  On a geometric graph this makes compact
+    // two-dimensional patches instead of slices of the one-dimensional RCM order: ~25 % smaller unions for the same rows,
+    // i.e. fewer bytes gathered into LDS per nonzero (the gathers run at the CU's L2 rate).
+    // MMW_BLK_GROW=0 keeps consecutive RCM rows.
+    const bool grow = !(getenv("MMW_BLK_GROW") && atoi(getenv("MMW_BLK_GROW")) == 0);
+    B.order.assign(K, -1);  // filled block by block: position -> original row
+    std::vector<char> assigned(K, 0);
+    std::vector<int32_t> in_union(K, 0), in_stamp(K, -1);  // neighbours of v inside the current union (valid for stamp == blk)
+    int seed_pos = 0;
     B.blk_rowptr.assign(1, 0);
     B.un_ptr.assign(1, 0);
     B.un_cols.clear();
@@ -151,8 +160,9 @@ inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& i
         cur.clear();
         int rows = 0, entries = 0;
         const int p_start = p;
+        while (assigned[rcm[seed_pos]]) ++seed_pos;
+        int r = rcm[seed_pos];
         while (p < K && rows < row_cap) {
-            const int r = B.order[p];
             int fresh = 0;
             for (int e = indptr[r]; e < indptr[r + 1]; ++e)
                 if (stamp[indices[e]] != blk) ++fresh;
@@ -161,17 +171,45 @@ inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& i
                              blk2_lds_need((int)cur.size() + fresh, entries + pe, lim.entry_bytes) > BLK2_LDS_BYTES))
                 break;
             entries += pe;
-            for (int e = indptr[r]; e < indptr[r + 1]; ++e)
-                if (stamp[indices[e]] != blk) {
-                    stamp[indices[e]] = blk;
-                    cur.push_back(indices[e]);
+            for (int e = indptr[r]; e < indptr[r + 1]; ++e) {
+                const int c = indices[e];
+                if (stamp[c] != blk) {
+                    stamp[c] = blk;
+                    cur.push_back(c);
+                    if (grow)
+                        for (int f = indptr[c]; f < indptr[c + 1]; ++f) {  // symmetric pattern: c's row lists who has c as a column
+                            const int v = indices[f];
+                            if (in_stamp[v] != blk) { in_stamp[v] = blk; in_union[v] = 0; }
+                            ++in_union[v];
+                        }
                 }
+            }
+            assigned[r] = 1;
+            B.order[p] = r;
             ++rows;
             ++p;
+            if (p >= K) break;
+            // next row
+            int best = -1;
+            if (grow) {
+                int best_fresh = INT32_MAX;
+                for (int c : cur)
+                    if (!assigned[c]) {
+                        const int fr = (indptr[c + 1] - indptr[c]) - (in_stamp[c] == blk ? in_union[c] : 0);
+                        if (fr < best_fresh || (fr == best_fresh && rank[c] < rank[best])) { best_fresh = fr; best = c; }
+                    }
+            } else {
+                while (seed_pos < K && assigned[rcm[seed_pos]]) ++seed_pos;
+                best = seed_pos < K ? rcm[seed_pos] : -1;
+            }
+            if (best < 0) break;  // the union holds no unassigned row (a finished component): next block, next seed
+            r = best;
         }
         if (row_quant > 1 && rows > row_quant && rows % row_quant && p < K) {  // trim to a multiple of the wave count
             const int keep = rows / row_quant * row_quant;
+            for (int q = p_start + keep; q < p; ++q) assigned[B.order[q]] = 0;
             p = p_start + keep;
+            seed_pos = 0;
             cur.clear();
             ++blk;  // fresh stamp generation for the rebuilt union
             for (int q = p_start; q < p; ++q) {
@@ -196,6 +234,8 @@ inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& i
             }
             if (p - p_start <= 1 || (exact <= max_entries_per_block && blk2_lds_need((int)cur.size(), exact, lim.entry_bytes) <= BLK2_LDS_BYTES)) break;
             --p;
+            assigned[B.order[p]] = 0;  // given back: it seeds or joins a later block
+            seed_pos = 0;
             cur.clear();
             ++blk;
             for (int q = p_start; q < p; ++q) {

@@ -463,7 +463,7 @@ struct Sd2Dev {
     const int* items;          // [nitems][3] {row block, first round, end round}
     int nitems;
 };
-constexpr int SD2_ROUNDS = 5;
+constexpr int SD2_ROUNDS = 4;  // rounds per work item (the host cuts longer blocks into several items)
 template <typename T>
 __global__ __launch_bounds__(SD2_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6)))  // <= 80 VGPRs: three workgroups per CU
 void k_sddmm_blk2(BlkDev B, Sd2Dev S, PatternDev<T> P, int Dpad, int ntiles,

@@ -107,6 +107,14 @@ template <typename T> struct Solver final : mmw_solver {
         if (host_only) {  // device == -1: pattern inspection only (CPU tests of the host logic)
             std::string lerr;
             if (make_layout(D, V16<T>::N, eng.lay, lerr) != MMW_OK) return fail(MMW_ERR_ARG, lerr);
+            if (getenv("MMW_HOST_BLOCKING")) {  // developer aid: build the locality blocking on the host and print its statistics
+                const double t0 = tnow();
+                build_blocking(HB, K, H.l_indptr, H.l_indices, BlockingLimits{blk_max_entries<T>(), (int)sizeof(BlkMeta<T>)});
+                fprintf(stderr, "[mmw] host blocking %.1f ms: usable %d half-tile %d blocks %d rows/block %.1f union/block %.1f reuse %.2f entries %lld (nnz %lld, +%.1f%% padding) sd2_rounds %d\n",
+                        (tnow() - t0) * 1e3, (int)HB.usable, (int)HB.fits_half_tile, HB.nb(), (double)K / std::max(1, HB.nb()),
+                        (double)HB.un_cols.size() / std::max(1, HB.nb()), HB.reuse, (long long)HB.nent, (long long)H.nnzL(),
+                        100.0 * ((double)HB.nent / (double)H.nnzL() - 1.0), HB.sd2_rounds);
+            }
             return MMW_OK;
         }
         MMW_HIP(hipSetDevice(device));
@@ -183,7 +191,7 @@ template <typename T> struct Solver final : mmw_solver {
             MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sddmm_blk<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
             sddmm_blk = true;
         }
-        if (HB.sd2_rounds <= SD2_ROUNDS && (double)K * eng.lay.Dpad * sizeof(T) < 4.0e9 && !getenv("MMW_FULL_TILE")) {
+        if ((double)K * eng.lay.Dpad * sizeof(T) < 4.0e9 && !getenv("MMW_FULL_TILE")) {
             MMW_TRY(b_sd2ptr.upload(HB.sd2_ptr, st)); MMW_TRY(b_sd2ab.upload(HB.sd2_ab, st)); MMW_TRY(b_sd2epos.upload(HB.sd2_epos, st));
             {   // Work items.  A workgroup is a latency chain whose length is its number of rounds, and the launch lasts as long
                 // as its longest workgroup; the resident slots the row blocks leave free are used to cut the longest items in two
@@ -197,7 +205,7 @@ template <typename T> struct Solver final : mmw_solver {
                 auto less = [&](const It& a, const It& b) { return len(a) != len(b) ? len(a) < len(b) : a.rb > b.rb; };
                 std::priority_queue<It, std::vector<It>, decltype(less)> pq(less);
                 for (int b = 0; b < HB.nb(); ++b) pq.push({b, 0, (HB.sd2_ptr[b + 1] - HB.sd2_ptr[b]) / SD2_THREADS});
-                while (pq.size() < slots && len(pq.top()) >= 2) {
+                while ((pq.size() < slots && len(pq.top()) >= 2) || len(pq.top()) > SD2_ROUNDS) {
                     const It t = pq.top();
                     pq.pop();
                     const int mid = t.k0 + (len(t) + 1) / 2;
