@@ -506,12 +506,14 @@ void k_sddmm_blk2(BlkDev B, Sd2Dev S, PatternDev<T> P, int Dpad, int ntiles,
     for (int j = 0; j < NG; ++j)
 #pragma unroll
         for (int v = 0; v < VEC; ++v) x[j][v] = T(0);
-    auto gather = [&](int t) {
+    auto gather_one = [&](int t, int j) {  // one 1-KiB piece (8 rows x 128 B) per wave
         const unsigned cb = (unsigned)(t * B2_ROW_BYTES);
-        const bool ok = t * CT + l8 * VEC < Dpad;  // only the last, partial tile tests lanes
+        const bool ok = t * CT + l8 * VEC < Dpad;  // only a last, partial tile tests lanes
+        if (wrow + j * RPP < nun8 && ok) load16(reinterpret_cast<const T*>(Ub + (gbase[j] + cb)), x[j]);
+    };
+    auto gather = [&](int t) {
 #pragma unroll
-        for (int j = 0; j < NG; ++j)
-            if (wrow + j * RPP < nun8 && ok) load16(reinterpret_cast<const T*>(Ub + (gbase[j] + cb)), x[j]);
+        for (int j = 0; j < NG; ++j) gather_one(t, j);
     };
     auto deposit = [&](bool full) {  // columns past Dpad are staged as zeros: every lane reads every chunk of its rows
 #pragma unroll
@@ -547,10 +549,16 @@ void k_sddmm_blk2(BlkDev B, Sd2Dev S, PatternDev<T> P, int Dpad, int ntiles,
     MMW_STAMP(4);
     const int skew = threadIdx.x & 7;
     for (int t = 0; t < ntiles; ++t) {
-        if (t + 1 < ntiles) gather(t + 1);
+        // the next tile's gathers are fed to the memory pipe a few at a time between the rounds: issued all at once they
+        // fill its queue and every wave stalls on issue (1.6 us per tile) before it can start on the LDS
+        constexpr int GPR = (NG + SD2_ROUNDS - 1) / SD2_ROUNDS;
         if (t == 0) MMW_STAMP(12);
 #pragma unroll
         for (int k = 0; k < SD2_ROUNDS; ++k) {
+            if (t + 1 < ntiles) {
+#pragma unroll
+                for (int j = k * GPR; j < (k + 1) * GPR && j < NG; ++j) gather_one(t + 1, j);
+            }
             if (k < rounds && ep[k] >= 0) {
                 Dot16<T> s;
                 const char* ra = tile + (ab[k] & 0xFFFFu) * B2_ROW_BYTES;
