@@ -384,4 +384,96 @@ inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& i
     B.usable = B.reuse >= 2.0 && fits_full;
 }
 
+// Invariants of a built blocking, checked on the host (CPU tests, MMW_CHECK_BLOCKING=1): every row in exactly one
+// block; every block's union holds all columns of its rows, in budget; the blocked entries are a permutation of the CSR
+// entries plus (row 0|1, idle) holes, chunk positions with bit 2 clear hold even staged rows and the others odd ones;
+// the SDDMM slots hold every upper-triangular entry once and paired lanes hold complementary row parities.
+inline std::string verify_blocking(const HostBlocking& B, int K, const std::vector<int32_t>& indptr, const std::vector<int32_t>& indices,
+                                   const BlockingLimits& lim) {
+    const int64_t nnz = indptr[K];
+    std::vector<char> seen(K, 0);
+    if ((int)B.order.size() != K) return "order has the wrong length";
+    for (int p = 0; p < K; ++p) {
+        const int r = B.order[p];
+        if (r < 0 || r >= K || seen[r]) return "order is not a permutation";
+        seen[r] = 1;
+    }
+    if (B.blk_rowptr.front() != 0 || B.blk_rowptr.back() != K) return "blocks do not cover the rows";
+    std::vector<int32_t> local(K, -1);
+    std::vector<char> ent_seen(nnz, 0), edge_seen(nnz, 0);
+    int64_t nupper = 0;
+    for (int k = 0; k < K; ++k)
+        for (int e = indptr[k]; e < indptr[k + 1]; ++e) nupper += indices[e] > k;
+    int64_t slots_used = 0;
+    for (int b = 0; b < B.nb(); ++b) {
+        const int u0 = B.un_ptr[b], u1 = B.un_ptr[b + 1], nun = u1 - u0;
+        if (nun < 1 || nun > BLK_UNION) return "union size out of range";
+        for (int u = u0; u < u1; ++u) {
+            if (local[B.un_cols[u]] >= 0) return "duplicate column in a union";
+            local[B.un_cols[u]] = u - u0;
+        }
+        const int32_t* d = &B.desc[(size_t)b * 8];
+        if (d[0] != B.blk_rowptr[b] || d[1] != B.blk_rowptr[b + 1] - B.blk_rowptr[b] || d[5] != nun) return "block record mismatch";
+        if (d[2] != B.bptr[d[0]] || d[3] != B.bptr[d[0] + d[1]] - B.bptr[d[0]]) return "block entry range mismatch";
+        if (d[1] > BLK_ROWS) return "too many rows in a block";
+        if (d[1] > 1 && (d[3] > lim.max_entries_per_block || blk2_lds_need(nun, d[3], lim.entry_bytes) > BLK2_LDS_BYTES) && B.fits_half_tile)
+            return "block over its LDS budget";
+        for (int q = B.blk_rowptr[b]; q < B.blk_rowptr[b + 1]; ++q) {
+            const int r = B.order[q];
+            if ((B.bptr[q + 1] - B.bptr[q]) % BLK_CHUNK) return "row not padded to whole chunks";
+            int real = 0;
+            for (int w = B.bptr[q]; w < B.bptr[q + 1]; ++w) {
+                const int pos = (w - B.bptr[q]) % BLK_CHUNK;
+                const bool odd_slot = (pos & 4) != 0;
+                if ((B.lidx[w] & 1) != (odd_slot ? 1 : 0)) return "staged-row parity does not match the chunk position";
+                const int e = B.bepos[w];
+                if (e < 0) continue;
+                if (e < indptr[r] || e >= indptr[r + 1] || ent_seen[e]) return "blocked entry maps to the wrong CSR position";
+                ent_seen[e] = 1;
+                if (local[indices[e]] != (int)B.lidx[w]) return "local index does not address the entry's column";
+                if (B.bpos[e] != w) return "bpos is not the inverse of bepos";
+                ++real;
+            }
+            if (real != indptr[r + 1] - indptr[r]) return "row lost entries";
+            if (local[r] >= 0 && B.self_li[q] != (uint16_t)local[r]) return "self index mismatch";
+        }
+        // SDDMM slots
+        const int s0 = B.sd2_ptr[b], s1 = B.sd2_ptr[b + 1];
+        if ((s1 - s0) % SD2_THREADS || s1 - s0 < SD2_THREADS) return "slot range is not whole rounds";
+        for (int sidx = s0; sidx < s1; ++sidx) {
+            const int e = B.sd2_epos[sidx];
+            if (e < 0) continue;
+            if (e >= nnz || edge_seen[e]) return "slot maps to a wrong or repeated entry";
+            edge_seen[e] = 1;
+            ++slots_used;
+            const int la = (int)(B.sd2_ab[sidx] & 0xFFFFu), lb = (int)(B.sd2_ab[sidx] >> 16);
+            // the entry's row is in this block and (la, lb) address {row, col} in either order
+            int row = -1;
+            {
+                int lo = 0, hi = K;  // row of CSR position e
+                while (hi - lo > 1) { const int mid = (lo + hi) / 2; (indptr[mid] <= e ? lo : hi) = mid; }
+                row = lo;
+            }
+            const int col = indices[e];
+            if (col <= row) return "slot holds a lower-triangular entry";
+            const bool straight = local[row] == la && local[col] == lb, swapped = local[row] == lb && local[col] == la;
+            if (!straight && !swapped) return "slot indices do not address the entry's rows";
+            // partner lane of the LDS service group
+            const int t = (sidx - s0) % SD2_THREADS, lane = t & 63, l32 = lane & 31;
+            int partner = -1;
+            if (l32 < 8) partner = lane + 24; else if (l32 < 16) partner = lane + 8; else if (l32 < 24) partner = lane - 8; else partner = lane - 24;
+            const int ps = sidx - lane + partner;
+            if (B.sd2_epos[ps] >= 0) {
+                const int pa = (int)(B.sd2_ab[ps] & 0xFFFFu), pb = (int)(B.sd2_ab[ps] >> 16);
+                if (((pa ^ la) & 1) == 0 || ((pb ^ lb) & 1) == 0) return "paired lanes read staged rows of equal parity";
+            }
+        }
+        for (int u = u0; u < u1; ++u) local[B.un_cols[u]] = -1;
+    }
+    for (int64_t e = 0; e < nnz; ++e)
+        if (!ent_seen[e]) return "a CSR entry is missing from the blocked arrays";
+    if (slots_used != nupper) return "the SDDMM slots do not hold every upper-triangular entry exactly once";
+    return "";
+}
+
 }  // namespace mmw

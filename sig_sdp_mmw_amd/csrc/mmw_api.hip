@@ -115,6 +115,14 @@ template <typename T> struct Solver final : mmw_solver {
                         (double)HB.un_cols.size() / std::max(1, HB.nb()), HB.reuse, (long long)HB.nent, (long long)H.nnzL(),
                         100.0 * ((double)HB.nent / (double)H.nnzL() - 1.0), HB.sd2_rounds);
             }
+            if (getenv("MMW_CHECK_BLOCKING")) {  // CPU tests: build the blocking and check its invariants
+                const BlockingLimits lim{blk_max_entries<T>(), (int)sizeof(BlkMeta<T>)};
+                if (HB.order.empty()) build_blocking(HB, K, H.l_indptr, H.l_indices, lim);
+                if (!HB.order.empty() && !HB.blk_rowptr.empty() && HB.blk_rowptr.back() == K) {
+                    const std::string berr = verify_blocking(HB, K, H.l_indptr, H.l_indices, lim);
+                    if (!berr.empty()) return fail(MMW_ERR_STATE, "blocking invariant violated: " + berr);
+                }
+            }
             return MMW_OK;
         }
         MMW_HIP(hipSetDevice(device));

@@ -91,3 +91,30 @@ def test_no_device_is_a_loud_error():
     from sig_sdp_mmw_amd.graphs import er_contention_graph
     with pytest.raises(_lib.MMWError):
         _lib.Solver(5, er_contention_graph(40, 0.2, 1), 3, 0.1, device=0)
+
+
+@pytest.mark.parametrize("kind", ["journal", "journal-dense", "er", "two-components", "tiny"])
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_locality_blocking_invariants_on_the_host(kind, dtype, monkeypatch):
+    """csrc/blocking.h: grown row blocks, parity-ordered chunks and parity-paired SDDMM slots, checked by the library's own
+    verifier on a host-only handle (every row in one block, unions cover the columns, entries a permutation, budgets,
+    complementary parities) -- no GPU needed."""
+    import scipy.sparse as sp
+    from sig_sdp_mmw_amd.graphs import er_contention_graph, journal_graph
+    if kind == "journal":
+        state = journal_graph(10, 0.02, seed=1)
+    elif kind == "journal-dense":
+        state = journal_graph(6, 0.3, seed=2)
+    elif kind == "er":
+        state = er_contention_graph(400, 0.05, 5)
+    elif kind == "tiny":
+        state = er_contention_graph(12, 0.5, 1)
+    else:  # two disconnected geometric components
+        a, b = journal_graph(6, 0.05, seed=3), journal_graph(5, 0.05, seed=4)
+        S = sp.block_diag([a[0], b[0]], format="csr")
+        Q = sp.block_diag([a[1], b[1]], format="csr")
+        state = (S, Q, np.concatenate([a[2], b[2]]))
+    monkeypatch.setenv("MMW_CHECK_BLOCKING", "1")
+    s = _lib.Solver(6, state, 3, 0.05, dtype=_lib.F32 if dtype == "f32" else _lib.F64, device=-1)  # raises MMWError on a violated invariant
+    assert s.K == state[0].shape[0]
+    s.close()
