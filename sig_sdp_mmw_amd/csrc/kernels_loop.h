@@ -463,15 +463,36 @@ struct Sd2Dev {
     const int* items;          // [nitems][3] {row block, first round, end round}
     int nitems;
 };
+// the next iteration's sketch rides in the SDDMM launch as extra workgroups (the SDDMM is a latency chain that leaves the
+// VALU idle; the Philox / Box-Muller work is pure VALU): nblocks == 0 disables it
+template <typename T> struct SketchArgs {
+    int nblocks, K, D;
+    uint64_t seed;
+    uint32_t iter;
+    T* R;
+    double* colsq_part;
+};
+template <typename T, int NWAVES>
+__device__ __forceinline__ void sketch_rows(int K, int D, int Dpad, uint64_t seed, uint32_t iter, T* __restrict__ R,
+                                            double* __restrict__ colsq_part, int bid, int nblocks, double* shc);
 constexpr int SD2_ROUNDS = 4;  // rounds per work item (the host cuts longer blocks into several items)
 template <typename T>
 __global__ __launch_bounds__(SD2_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6)))  // <= 80 VGPRs: three workgroups per CU
 void k_sddmm_blk2(BlkDev B, Sd2Dev S, PatternDev<T> P, int Dpad, int ntiles,
                                                             const T* __restrict__ Yb, const T* __restrict__ d,
                                                             const double* __restrict__ tr_part, int ntr, T* __restrict__ xval,
-                                                            T* __restrict__ xavg, int accumulate, unsigned long long* __restrict__ stamps) {
+                                                            T* __restrict__ xavg, int accumulate, SketchArgs<T> sk, unsigned long long* __restrict__ stamps) {
     constexpr int VEC = V16<T>::N;
     constexpr int CT = B2_ROW_BYTES / (int)sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    {
+        const int grid_sd = (S.nitems + 7) / 8 * 8;
+        if ((int)blockIdx.x >= grid_sd) {  // appended sketch workgroups (dispatched last: they fill the slots the items leave)
+            sketch_rows<T, SD2_THREADS / WAVE>(sk.K, sk.D, Dpad, sk.seed, sk.iter, sk.R, sk.colsq_part, (int)blockIdx.x - grid_sd, sk.nblocks,
+                                               reinterpret_cast<double*>(smem_raw));
+            return;
+        }
+    }
 #define MMW_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     MMW_STAMP(0);
     if (stamps && threadIdx.x == 0) {
@@ -481,7 +502,6 @@ void k_sddmm_blk2(BlkDev B, Sd2Dev S, PatternDev<T> P, int Dpad, int ntiles,
     constexpr int RPP = SD2_THREADS / 8;
     constexpr int NG = (BLK_UNION_ROWS + RPP - 1) / RPP;
     constexpr int NW = SD2_THREADS / WAVE;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* tile = smem_raw;
     __shared__ double sh[NW];
     double tsum = 0.0;
@@ -626,13 +646,13 @@ __device__ __forceinline__ void normals16(const uint32_t (&w)[4], float (&n)[4])
 }
 __device__ __forceinline__ void normals16(const uint32_t (&w)[4], double (&n)[2]) { box_muller(w, n[0], n[1]); }
 
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_sketch_rng(int K, int D, int Dpad, uint64_t seed, uint32_t iter, T* __restrict__ R,
-                                                      double* __restrict__ colsq_part) {
+// body shared by k_sketch_rng and by the sketch workgroups appended to the SDDMM launch (NWAVES waves per workgroup,
+// `bid` of `nblocks` workgroups, `shc` = NWAVES x Dpad doubles of LDS when colsq_part)
+template <typename T, int NWAVES>
+__device__ __forceinline__ void sketch_rows(int K, int D, int Dpad, uint64_t seed, uint32_t iter, T* __restrict__ R,
+                                            double* __restrict__ colsq_part, int bid, int nblocks, double* shc) {
     constexpr int VEC = V16<T>::N;
     constexpr int NS = 4;  // 64 lanes x 4 steps x 16 B covers Dpad <= 1024 floats / 512 doubles
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double* shc = reinterpret_cast<double*>(smem_raw);  // [WAVES_PER_BLOCK][Dpad] when colsq_part
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int ngroups = Dpad / VEC;
     T csq[NS][VEC];  // a wave sums a handful of unit-norm rows: T is enough, widened once at the end
@@ -640,7 +660,11 @@ __global__ __launch_bounds__(BLOCK) void k_sketch_rng(int K, int D, int Dpad, ui
     for (int i = 0; i < NS; ++i)
 #pragma unroll
         for (int v = 0; v < VEC; ++v) csq[i][v] = T(0);
-    for (int row = blockIdx.x * WAVES_PER_BLOCK + wib; row < K; row += gridDim.x * WAVES_PER_BLOCK) {
+    // a workgroup of NWAVES waves stands for NWAVES/4 workgroups of the stand-alone kernel (same rows per wave, same slabs),
+    // so the start norms do not depend on which launch drew the sketch
+    constexpr int VB = NWAVES / WAVES_PER_BLOCK;
+    const int vb = bid * VB + wib / WAVES_PER_BLOCK, vw = wib % WAVES_PER_BLOCK;
+    for (int row = vb * WAVES_PER_BLOCK + vw; row < K; row += nblocks * VB * WAVES_PER_BLOCK) {
         T n[NS][VEC];
         T ssl = T(0);
 #pragma unroll
@@ -683,12 +707,20 @@ __global__ __launch_bounds__(BLOCK) void k_sketch_rng(int K, int D, int Dpad, ui
                 for (int v = 0; v < VEC; ++v) shc[wib * Dpad + p * VEC + v] = (double)csq[i][v];
         }
         __syncthreads();
-        for (int c = threadIdx.x; c < Dpad; c += BLOCK) {
+        for (int i = threadIdx.x; i < VB * Dpad; i += NWAVES * WAVE) {
+            const int h = i / Dpad, c = i - h * Dpad;
             double t = 0.0;
-            for (int w = 0; w < WAVES_PER_BLOCK; ++w) t += shc[w * Dpad + c];
-            colsq_part[(size_t)blockIdx.x * Dpad + c] = t;
+            for (int w = 0; w < WAVES_PER_BLOCK; ++w) t += shc[(h * WAVES_PER_BLOCK + w) * Dpad + c];
+            colsq_part[(size_t)(bid * VB + h) * Dpad + c] = t;
         }
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_sketch_rng(int K, int D, int Dpad, uint64_t seed, uint32_t iter, T* __restrict__ R,
+                                                      double* __restrict__ colsq_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    sketch_rows<T, WAVES_PER_BLOCK>(K, D, Dpad, seed, iter, R, colsq_part, blockIdx.x, gridDim.x, reinterpret_cast<double*>(smem_raw));
 }
 
 template <typename T> __global__ __launch_bounds__(BLOCK) void k_fill(size_t n, T* __restrict__ a, T v) {

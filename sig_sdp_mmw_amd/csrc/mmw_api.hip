@@ -61,6 +61,9 @@ template <typename T> struct Solver final : mmw_solver {
     int sd2_nitems = 0;
     DevBuf<unsigned> b_sd2ab;
     bool sddmm_blk2 = false;  // half-tile SDDMM (k_sddmm_blk2)
+    int64_t sketch_done_for = -1;  // iteration whose sketch the last SDDMM launch already drew into the start block
+    uint64_t sketch_done_seed = 0;
+    int sketch_done_slabs = 0;
     DevBuf<T> lval_blk;
     int blocking_mode = 1;  // 1: use when profitable, 0: never
     // optimistic (no per-iteration readback) batches: snapshot for the rare replay
@@ -505,6 +508,8 @@ template <typename T> struct Solver final : mmw_solver {
         const int gl = (int)std::min<size_t>(((size_t)H.nnzL() + BLOCK - 1) / BLOCK, (size_t)LOSS_GRID_MAX);  // LOSS: one thread per stored entry
         const int Dpad = eng.lay.Dpad;
         int m_launch = optimistic ? m_guess : 0;
+        const bool fuse_sketch = !kt.on && !timing && !getenv("MMW_NO_FUSED_SKETCH");  // profiling keeps the kernels apart
+        sketch_done_for = -1;  // whatever an earlier batch left in the start block is not trusted
         for (int it = 0; it < n; ++it) {
             if (optimistic && it > 0 && it % 16 == 0) {  // cheap periodic look at the device-side order
                 int viol = 0;
@@ -534,9 +539,11 @@ template <typename T> struct Solver final : mmw_solver {
                 hipLaunchKernelGGL((k_import_block<T>), dim3(grid_elems(eng.bs)), dim3(BLOCK), 0, st, K, D, Dpad, stage64.p, eng.start_block());
                 last_was_rng = false;
             } else {
-                MMW_TRY(launch_sketch(st, seed, (uint32_t)iter));
+                const bool have = sketch_done_for == (int64_t)iter && sketch_done_seed == seed;  // drawn by the previous SDDMM launch
+                if (!have) MMW_TRY(launch_sketch(st, seed, (uint32_t)iter));
                 eng.start_colsq_ready = eng.method == MMW_EXPM_LANCZOS;  // the Lanczos start norms come out of the sketch kernel
-                eng.npart_start = sketch_slabs();
+                eng.npart_start = have ? sketch_done_slabs : sketch_slabs();
+                sketch_done_for = -1;
                 last_was_rng = true;
                 last_seed = seed;
             }
@@ -560,8 +567,21 @@ template <typename T> struct Solver final : mmw_solver {
                 S.ptr = b_sd2ptr.p; S.ab = b_sd2ab.p; S.epos = b_sd2epos.p; S.items = b_sd2items.p; S.nitems = sd2_nitems;
                 constexpr int CT2 = B2_ROW_BYTES / (int)sizeof(T);
                 const int per = (sd2_nitems + 7) / 8;
-                hipLaunchKernelGGL((k_sddmm_blk2<T>), dim3(per * 8), dim3(SD2_THREADS), (size_t)HB.un8_max * B2_ROW_BYTES, st, blkdev(), S, P, Dpad,
-                                   (Dpad + CT2 - 1) / CT2, Xh.p, drow.p, tr_part.p, gr, xval.p, xavg.p, acc, sd_stamps);
+                SketchArgs<T> sk{};
+                const size_t sd_lds = (size_t)HB.un8_max * B2_ROW_BYTES;
+                const bool lzm = eng.method == MMW_EXPM_LANCZOS;
+                if (fuse_sketch && !randv && it + 1 < n && (size_t)(SD2_THREADS / WAVE) * Dpad * sizeof(double) <= sd_lds) {
+                    // the start block and its norm slabs are free once the combination has run: draw the next iteration's sketch here
+                    sk.nblocks = (sketch_slabs() + 1) / 2;  // 8-wave workgroups, each standing for two of the stand-alone kernel's
+                    sk.K = K; sk.D = D; sk.seed = seed; sk.iter = (uint32_t)(iter + 1);
+                    sk.R = eng.start_block();
+                    sk.colsq_part = lzm ? eng.partial_sq.p : nullptr;
+                    sketch_done_for = (int64_t)iter + 1;
+                    sketch_done_seed = seed;
+                    sketch_done_slabs = sk.nblocks * 2;
+                }
+                hipLaunchKernelGGL((k_sddmm_blk2<T>), dim3(per * 8 + sk.nblocks), dim3(SD2_THREADS), sd_lds, st, blkdev(), S, P, Dpad,
+                                   (Dpad + CT2 - 1) / CT2, Xh.p, drow.p, tr_part.p, gr, xval.p, xavg.p, acc, sk, sd_stamps);
                 if (sd_stamps) MMW_TRY(dump_stamps(sd_stamps));
             } else if (sddmm_blk && eng.use_blk) {
                 SdDev S;
