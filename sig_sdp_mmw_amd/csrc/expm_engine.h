@@ -49,8 +49,8 @@ inline int spmm_launch(hipStream_t st, int K, const BlockLayout& lay, int nblk, 
 }
 
 // Static schedule of the half-tile SpMM.  Two workgroups are resident per CU and a workgroup is latency-bound (it takes
-// about the same time alone or paired), so the launch is cut into ~4 rounds of short workgroups: tile groups of
-// nb * ntiles / (4 * slots) tiles.  Short workgroups re-stage the block's entries once per tile group (fabric traffic
+// about the same time alone or paired), so the launch is cut into ~2.5 rounds of short workgroups: tile groups of
+// nb * ntiles / (2.5 * slots) tiles.  Short workgroups re-stage the block's entries once per tile group (fabric traffic
 // 79 MB vs 41 MB algorithmic at the bench config, all of it Infinity-Cache hits) but two co-resident workgroups in
 // different phases interleave better than two long ones in lockstep: whole blocks first and only the last partial
 // round cut into pieces (MMW_SCHED=2) moves 40 % fewer bytes and measures 5 % slower.
@@ -64,7 +64,7 @@ inline Blk2Sched blk2_schedule(int nb, int ntiles) {
     Blk2Sched s;
     static const bool two_phase = getenv("MMW_SCHED") && atoi(getenv("MMW_SCHED")) == 2;
     if (!two_phase) {
-        int tpw = (int)((double)nb * ntiles / (4.0 * slots) + 0.5);
+        int tpw = (int)((double)nb * ntiles / (2.5 * slots) + 0.5);  // 2.5-4 rounds measure the same; fewer groups re-stage less
         if (const char* e = getenv("MMW_TPW")) tpw = atoi(e);
         tpw = tpw < 1 ? 1 : (tpw > ntiles ? ntiles : tpw);
         s.nfull = 0; s.grid1 = 0; s.tpw_tail = tpw; s.groups_tail = (ntiles + tpw - 1) / tpw;
