@@ -610,11 +610,7 @@ void k_sddmm_blk2(BlkDev B, Sd2Dev S, PatternDev<T> P, int Dpad, int ntiles,
             const T xv = (T)((double)acc[k] / tr);
             const int e = ep[k], me = P.mirror[e];
             xval[e] = xv;
-            xval[me] = xv;
-            if (accumulate) {
-                xavg[e] += xv;
-                xavg[me] += xv;
-            }
+            xval[me] = xv;  // the running sum xavg += xval is a coalesced pass of its own (k_accumulate), not 2 more scattered RMWs here
         }
     const int q0 = B.rowptr[rb], q1 = k0 == 0 ? B.rowptr[rb + 1] : B.rowptr[rb];  // the item with the first round writes the diagonal
     for (int q = q0 + threadIdx.x; q < q1; q += SD2_THREADS) {
@@ -622,7 +618,10 @@ void k_sddmm_blk2(BlkDev B, Sd2Dev S, PatternDev<T> P, int Dpad, int ntiles,
         const int dp = P.diag_pos[row];
         const T xd = (T)((double)d[row] / tr);
         xval[dp] = xd;
-        if (accumulate) xavg[dp] += xd;
+    }
+    if (stamps) {  // diagnostic runs: the end stamp waits for every wave's stores to be issued
+        MMW_STAMP(13);
+        __syncthreads();
     }
     MMW_STAMP(9);
 #undef MMW_STAMP
@@ -723,6 +722,10 @@ __global__ __launch_bounds__(BLOCK) void k_sketch_rng(int K, int D, int Dpad, ui
     sketch_rows<T, WAVES_PER_BLOCK>(K, D, Dpad, seed, iter, R, colsq_part, blockIdx.x, gridDim.x, reinterpret_cast<double*>(smem_raw));
 }
 
+// xavg += xval over the whole pattern (the running sum of X; coalesced, 12 bytes per stored entry)
+template <typename T> __global__ __launch_bounds__(BLOCK) void k_accumulate(size_t n, const T* __restrict__ x, T* __restrict__ sum) {
+    for (size_t o = (size_t)blockIdx.x * BLOCK + threadIdx.x; o < n; o += (size_t)gridDim.x * BLOCK) sum[o] += x[o];
+}
 template <typename T> __global__ __launch_bounds__(BLOCK) void k_fill(size_t n, T* __restrict__ a, T v) {
     for (size_t o = (size_t)blockIdx.x * BLOCK + threadIdx.x; o < n; o += (size_t)gridDim.x * BLOCK) a[o] = v;
 }

@@ -313,6 +313,22 @@ template <typename T> struct Solver final : mmw_solver {
                     if (q[0] && q[9]) dur.push_back((double)(q[9] - q[0]) * 0.01);
                 }
                 std::sort(dur.begin(), dur.end());
+                {   // the ten longest workgroups: when they started, how long they ran, where
+                    std::vector<std::pair<double, int>> byd;
+                    for (int w = 0; w < 8192; ++w) {
+                        const unsigned long long* q = &h[(size_t)w * 16];
+                        if (q[0] && q[9]) byd.push_back({(double)(q[9] - q[0]) * 0.01, w});
+                    }
+                    std::sort(byd.rbegin(), byd.rend());
+                    for (size_t i = 0; i < byd.size() && i < 10; ++i) {
+                        const unsigned long long* q = &h[(size_t)byd[i].second * 16];
+                        fprintf(stderr, "[stamps]   wg %4d start +%.1f us dur %.1f us first-tile %.1f us cu %llx\n", byd[i].second, (double)(q[0] - tmin) * 0.01,
+                                byd[i].first, q[5] && q[4] ? (double)(q[5] - q[4]) * 0.01 : 0.0, ((q[11] & 0xF) << 16) | (q[10] & 0xFF00));
+                    }
+                    double late = 0; int nl = 0;
+                    for (auto& pr : byd) { const unsigned long long* q = &h[(size_t)pr.second * 16]; const double st0 = (double)(q[0] - tmin) * 0.01; if (st0 > 5.0) { late += st0; ++nl; } }
+                    fprintf(stderr, "[stamps]   %d workgroups started later than +5 us (mean +%.1f us)\n", nl, nl ? late / nl : 0.0);
+                }
                 if (!dur.empty())
                     fprintf(stderr, "[stamps] workgroup us: min %.1f p25 %.1f p50 %.1f p75 %.1f p95 %.1f max %.1f\n", dur.front(), dur[dur.size() / 4],
                             dur[dur.size() / 2], dur[dur.size() * 3 / 4], dur[dur.size() * 95 / 100], dur.back());
@@ -583,6 +599,7 @@ template <typename T> struct Solver final : mmw_solver {
                 hipLaunchKernelGGL((k_sddmm_blk2<T>), dim3(per * 8 + sk.nblocks), dim3(SD2_THREADS), sd_lds, st, blkdev(), S, P, Dpad,
                                    (Dpad + CT2 - 1) / CT2, Xh.p, drow.p, tr_part.p, gr, xval.p, xavg.p, acc, sk, sd_stamps);
                 if (sd_stamps) MMW_TRY(dump_stamps(sd_stamps));
+                if (acc) hipLaunchKernelGGL((k_accumulate<T>), dim3((unsigned)std::min<size_t>(((size_t)H.nnzL() + BLOCK - 1) / BLOCK, 4096)), dim3(BLOCK), 0, st, (size_t)H.nnzL(), xval.p, xavg.p);
             } else if (sddmm_blk && eng.use_blk) {
                 SdDev S;
                 S.ptr = b_sdptr.p; S.la = b_sdla.p; S.lb = b_sdlb.p; S.epos = b_sdepos.p;
