@@ -233,7 +233,6 @@ __global__ __launch_bounds__(BLOCK) void k_sddmm(PatternDev<T> P, int Dpad, int 
         if (lane == 0) {
             const T xd = (T)((double)d[row] / tr);
             xval[dp] = xd;
-            if (accumulate) xavg[dp] += xd;
         }
         // entries right of the diagonal are the upper-triangular edges of this row; UNR edges per lane group are in
         // flight at once (the loop is latency-bound on the gathers otherwise)
@@ -283,10 +282,6 @@ __global__ __launch_bounds__(BLOCK) void k_sddmm(PatternDev<T> P, int Dpad, int 
                     const int me = P.mirror[e];
                     xval[e] = x;
                     xval[me] = x;
-                    if (accumulate) {
-                        xavg[e] += x;
-                        xavg[me] += x;
-                    }
                 }
             } else {
 #pragma unroll
@@ -301,10 +296,6 @@ __global__ __launch_bounds__(BLOCK) void k_sddmm(PatternDev<T> P, int Dpad, int 
                         const int me = P.mirror[ee[u]];
                         xval[ee[u]] = x;
                         xval[me] = x;
-                        if (accumulate) {
-                            xavg[ee[u]] += x;
-                            xavg[me] += x;
-                        }
                     }
             }
         }
@@ -434,10 +425,6 @@ __global__ __launch_bounds__(BLK_THREADS) void k_sddmm_blk(BlkDev B, SdDev S, Pa
             const int e = ep[k], me = P.mirror[e];
             xval[e] = xv;
             xval[me] = xv;
-            if (accumulate) {
-                xavg[e] += xv;
-                xavg[me] += xv;
-            }
         }
     // diagonal of the block's rows
     const int q0 = B.rowptr[rb], q1 = B.rowptr[rb + 1];
@@ -446,7 +433,6 @@ __global__ __launch_bounds__(BLK_THREADS) void k_sddmm_blk(BlkDev B, SdDev S, Pa
         const int dp = P.diag_pos[row];
         const T xd = (T)((double)d[row] / tr);
         xval[dp] = xd;
-        if (accumulate) xavg[dp] += xd;
     }
 }
 

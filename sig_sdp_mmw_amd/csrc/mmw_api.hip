@@ -599,7 +599,6 @@ template <typename T> struct Solver final : mmw_solver {
                 hipLaunchKernelGGL((k_sddmm_blk2<T>), dim3(per * 8 + sk.nblocks), dim3(SD2_THREADS), sd_lds, st, blkdev(), S, P, Dpad,
                                    (Dpad + CT2 - 1) / CT2, Xh.p, drow.p, tr_part.p, gr, xval.p, xavg.p, acc, sk, sd_stamps);
                 if (sd_stamps) MMW_TRY(dump_stamps(sd_stamps));
-                if (acc) hipLaunchKernelGGL((k_accumulate<T>), dim3((unsigned)std::min<size_t>(((size_t)H.nnzL() + BLOCK - 1) / BLOCK, 4096)), dim3(BLOCK), 0, st, (size_t)H.nnzL(), xval.p, xavg.p);
             } else if (sddmm_blk && eng.use_blk) {
                 SdDev S;
                 S.ptr = b_sdptr.p; S.la = b_sdla.p; S.lb = b_sdlb.p; S.epos = b_sdepos.p;
@@ -615,6 +614,8 @@ template <typename T> struct Solver final : mmw_solver {
                 case 3: hipLaunchKernelGGL((k_sddmm<T, 3>), dim3(gr), dim3(BLOCK), 0, st, P, Dpad, eng.lay.LPR, eng.lay.G, Xh.p, drow.p, tr_part.p, gr, xval.p, xavg.p, acc); break;
                 default: hipLaunchKernelGGL((k_sddmm<T, 4>), dim3(gr), dim3(BLOCK), 0, st, P, Dpad, eng.lay.LPR, eng.lay.G, Xh.p, drow.p, tr_part.p, gr, xval.p, xavg.p, acc); break;
             }
+            // the running sum of X (mmw.py:77-78): one coalesced pass; none of the SDDMM kernels read-modify-writes xavg
+            if (acc) hipLaunchKernelGGL((k_accumulate<T>), dim3((unsigned)std::min<size_t>(((size_t)H.nnzL() + BLOCK - 1) / BLOCK, 4096)), dim3(BLOCK), 0, st, (size_t)H.nnzL(), xval.p, xavg.p);
             MMW_TRY(kt.end());
             MMW_HIP(hipGetLastError());
             MMW_TRY(record(3));
