@@ -113,7 +113,7 @@ inline std::vector<int32_t> rcm_order(int K, const std::vector<int32_t>& indptr,
 // LDS budget of the half-tile kernel (k_spmm_blk2: two workgroups per CU): a fixed header, the union's rows at
 // 128 B each, then the block's staged entries
 constexpr int BLK2_LDS_BYTES = 79872;
-constexpr int BLK2_HEADER_BYTES = 4864;
+constexpr int BLK2_HEADER_BYTES = 5120;
 constexpr int BLK2_ROW_BYTES = 128;
 constexpr int SD2_THREADS = 512;     // workgroup size of the half-tile SDDMM
 struct BlockingLimits {

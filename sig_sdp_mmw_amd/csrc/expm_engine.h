@@ -87,7 +87,8 @@ inline unsigned long long* g_blk_stamps = nullptr;  // diagnostic builds only: p
 // one launch of the LDS-staged blocked SpMM (values in blocked order)
 template <typename T, int MODE>
 inline int spmm_blk_launch(hipStream_t st, const BlkDev& B, int Dpad, const T* val_blk, const T* in, T* out, T* F, const T* X2,
-                           double c1, double c2, double c3, double* partial, const ExpmPlan* plan = nullptr, int step = 0) {
+                           double c1, double c2, double c3, double* partial, const ExpmPlan* plan = nullptr, int step = 0,
+                           double* partial_o2 = nullptr) {
     if (B.half_tile) {
         constexpr int CT2 = B2_ROW_BYTES / (int)sizeof(T);
         const int ntiles = (Dpad + CT2 - 1) / CT2;
@@ -99,7 +100,7 @@ inline int spmm_blk_launch(hipStream_t st, const BlkDev& B, int Dpad, const T* v
             MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_blk2<T, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS_BYTES));
             attr2_set = true;
         }
-        hipLaunchKernelGGL((k_spmm_blk2<T, MODE>), dim3(grid), dim3(B2_THREADS), B2_LDS_BYTES, st, B, Dpad, ntiles, sched, val_blk, in, out, F, X2, c1, c2, c3, partial, plan, step, g_blk_stamps);
+        hipLaunchKernelGGL((k_spmm_blk2<T, MODE>), dim3(grid), dim3(B2_THREADS), B2_LDS_BYTES, st, B, Dpad, ntiles, sched, val_blk, in, out, F, X2, c1, c2, c3, partial, partial_o2, plan, step, g_blk_stamps);
         MMW_HIP(hipGetLastError());
         return MMW_OK;
     }
@@ -133,7 +134,7 @@ template <typename T> struct ExpmEngine {
     const T* val = nullptr;
     DevBuf<T> U;        // (max_order + 1) blocks of K*Dpad; block 0 is the start block
     DevBuf<T> Tm;       // A * U_j
-    DevBuf<double> partial, partial_sq, colsum, scal, row_part;  // partial: alpha numerators; partial_sq: column sums of squares
+    DevBuf<double> partial, partial_sq, partial_o2, colsum, scal, row_part;  // partial_o2: column sums of squares of the product (a-posteriori stop)  // partial: alpha numerators; partial_sq: column sums of squares
     DevBuf<ExpmPlan> plan_d;
     DevBuf<int> viol_d;
     ExpmPlan* plan_h = nullptr;  // pinned
@@ -148,6 +149,8 @@ template <typename T> struct ExpmEngine {
     double* rownorm_part = nullptr;
     bool start_colsq_ready = false;  // the producer of the start block already filled `partial` with its column sums of squares (npart_start slabs)
     int npart_start = 0;
+    // the a-posteriori stop rides on the half-tile SpMM's shifted Lanczos epilogue
+    bool apost() const { static const bool off = getenv("MMW_NO_APOST") != nullptr; return use_blk && blk.half_tile && method == MMW_EXPM_LANCZOS && !off; }
     int kbegin(int slot) { return kt ? kt->begin(slot) : MMW_OK; }
     int kend() { return kt ? kt->end() : MMW_OK; }
 
@@ -174,6 +177,7 @@ template <typename T> struct ExpmEngine {
         MMW_TRY(Tm.alloc(bs));
         MMW_TRY(partial.alloc((size_t)MAX_PART * lay.Dpad));
         MMW_TRY(partial_sq.alloc((size_t)MAX_PART * lay.Dpad));
+        MMW_TRY(partial_o2.alloc((size_t)MAX_PART * lay.Dpad));
         npart = nblk;
         MMW_TRY(colsum.alloc(lay.Dpad));
         MMW_TRY(scal.alloc((size_t)4 * (MAX_ORDER + 2) * lay.Dpad));
@@ -217,7 +221,8 @@ template <typename T> struct ExpmEngine {
                                         const ExpmPlan* plan = nullptr, int step = 0) {
         MMW_TRY(kbegin(KT_SPMM));
         if (use_blk)
-            MMW_TRY((spmm_blk_launch<T, MODE>(st, blk, lay.Dpad, val_blk, in, out, F, nullptr, ascale, shift, inv_k, partial.p, plan, step)));
+            MMW_TRY((spmm_blk_launch<T, MODE>(st, blk, lay.Dpad, val_blk, in, out, F, nullptr, ascale, shift, inv_k, partial.p, plan, step,
+                                              apost() ? partial_o2.p : nullptr)));
         else
             MMW_TRY((spmm_launch<T, MODE>(st, K, lay, nblk, indptr, col, val, in, out, F, nullptr, ascale, shift, inv_k, partial.p, plan, step)));
         return kend();
@@ -227,7 +232,10 @@ template <typename T> struct ExpmEngine {
         val_blk = values_blocked;
         use_blk = true;
         npart = b.nb;
-        if ((size_t)b.nb > (size_t)MAX_PART) MMW_TRY(partial.alloc((size_t)b.nb * lay.Dpad));
+        if ((size_t)b.nb > (size_t)MAX_PART) {
+            MMW_TRY(partial.alloc((size_t)b.nb * lay.Dpad));
+            MMW_TRY(partial_o2.alloc((size_t)b.nb * lay.Dpad));
+        }
         return MMW_OK;
     }
     template <int OP> int colreduce(int nb, int j, const ExpmPlan* plan) {
@@ -243,7 +251,7 @@ template <typename T> struct ExpmEngine {
     //                themselves skip the stages beyond the device-side order (viol is raised if it needs more).
     int make_plan(double ascale, int m_launch) {
         hipLaunchKernelGGL((k_rowsums<T>), dim3(nwide), dim3(BLOCK), 0, st, K, indptr, col, val, ascale, row_part.p);
-        hipLaunchKernelGGL(k_plan, dim3(1), dim3(PLAN_THREADS), 0, st, K, method, max_order, tol, row_part.p, nwide, plan_d.p, m_launch, viol_d.p);
+        hipLaunchKernelGGL(k_plan, dim3(1), dim3(PLAN_THREADS), 0, st, K, method, max_order, tol, row_part.p, nwide, plan_d.p, m_launch, viol_d.p, apost() ? 1 : 0);
         MMW_HIP(hipGetLastError());
         if (m_launch > 0) return MMW_OK;
         MMW_HIP(hipMemcpyAsync(plan_h, plan_d.p, sizeof(ExpmPlan), hipMemcpyDeviceToHost, st));
@@ -259,6 +267,12 @@ template <typename T> struct ExpmEngine {
         MMW_HIP(hipMemcpyAsync(&v, viol_d.p, sizeof(int), hipMemcpyDeviceToHost, st));
         MMW_HIP(hipStreamSynchronize(st));
         last = *plan_h;
+        if (getenv("MMW_VERBOSE")) {
+            union { unsigned u; float f; } c1, c2;
+            c1.u = last.conv[1]; c2.u = last.conv[2];
+            fprintf(stderr, "[plan] rho %.3e tol %.1e m %d (a-priori %d) apost %d m_eff %d est[1] %.3e est[2] %.3e viol %d\n", last.rho, last.tol, last.m,
+                    last.m_apriori, last.apost, last.m_eff, c1.f, c2.f, v);
+        }
         if (violated) *violated = v;
         return MMW_OK;
     }
@@ -273,7 +287,7 @@ template <typename T> struct ExpmEngine {
         const int m = m_launch > 0 ? m_launch : last.m;
         const int nsub = m_launch > 0 ? 1 : last.nsub;
         MMW_TRY(ensure_blocks(std::max(3, m)));
-        const ExpmPlan* pd = plan_d.p;
+        ExpmPlan* pd = plan_d.p;
         const int Dpad = lay.Dpad;
         const int gcol = (Dpad + 63) / 64;
         const int gel = grid_elems(bs);
@@ -298,8 +312,18 @@ template <typename T> struct ExpmEngine {
                     MMW_TRY((launch_spmm<SPMM_LANCZOS>(block(j - 1), Tm.p, nullptr, ascale, 0.0, 1.0, pd, j)));
                     MMW_TRY(kbegin(KT_KRYLOV_VEC));
                     // one launch: the norms of U_j, alpha_j, and after the last product the small exponentials
-                    hipLaunchKernelGGL(k_lz_scalars, dim3((Dpad + LZS_COLS - 1) / LZS_COLS), dim3(1024), 0, st, npart, partial.p, nsq, partial_sq.p, Dpad, j, m,
+                    hipLaunchKernelGGL(k_lz_scalars, dim3((Dpad + LZS_COLS - 1) / LZS_COLS), dim3(1024), 0, st, npart, partial.p,
+                                       apost() ? partial_o2.p : (double*)nullptr, nsq, partial_sq.p, Dpad, j, m,
                                        1.0 / nsub, eps, S, pd);
+                    if (kt && kt->on && apost() && j < m) {  // profiling counts exact launches: look at the estimate before going on
+                        MMW_TRY(kend());
+                        MMW_HIP(hipMemcpyAsync(plan_h, plan_d.p, sizeof(ExpmPlan), hipMemcpyDeviceToHost, st));
+                        MMW_HIP(hipStreamSynchronize(st));
+                        union { float f; unsigned u; } tb;
+                        tb.f = (float)plan_h->tol;
+                        if (plan_h->apost && plan_h->conv[j] <= tb.u) break;
+                        MMW_TRY(kbegin(KT_KRYLOV_VEC));
+                    }
                     if (j < m) {  // the last product A U_m goes straight into the combination (corrected scheme)
                         hipLaunchKernelGGL((k_lz_update<T>), dim3(gr), dim3(BLOCK), shcol, st, K, Dpad, j, Tm.p, block(j - 1),
                                            j > 1 ? block(j - 2) : block(j - 1), block(j), S, partial_sq.p, pd);
@@ -310,7 +334,7 @@ template <typename T> struct ExpmEngine {
                 MMW_TRY(kbegin(KT_KRYLOV_VEC));
                 const bool last = sub + 1 == nsub;
                 hipLaunchKernelGGL((k_lz_combine<T>), dim3(nwide), dim3(BLOCK), 0, st, K, Dpad, m, U.p, bs, Tm.p, S.coef, out, pd,
-                                   last ? rownorm_d : (T*)nullptr, last ? rownorm_part : (double*)nullptr);
+                                   last ? rownorm_d : (T*)nullptr, last ? rownorm_part : (double*)nullptr, viol_d.p);
                 MMW_TRY(kend());
             } else {
                 hipLaunchKernelGGL((k_copy<T>), dim3(gel), dim3(BLOCK), 0, st, bs, U.p, out);

@@ -21,11 +21,30 @@ struct BlockLayout {
 struct ExpmPlan {      // written by k_plan, read by every expm kernel
     double rho;        // bound on || A - mu I ||_1
     double mu;         // trace(A)/K
-    int m;             // Krylov order / Taylor degree per substep
+    double tol;
+    int m;             // Krylov order / Taylor degree per substep (never more than the host launched)
     int nsub;          // substeps (time stepping exp(A) = exp(A/nsub)^nsub)
     int overflow;      // 1 when max_order could not meet tol
-    int pad;
+    int m_apriori;     // the order the a-priori bound asks for
+    int apost;         // 1: the Lanczos steps carry an a-posteriori error estimate and stop as soon as it meets tol
+    int m_eff;         // steps the last application actually used (written by the combination)
+    unsigned conv[MAX_ORDER + 2];  // conv[j]: float bits of the largest per-column estimate after j steps (valid once step j's scalars ran)
 };
+// Steps that run, given the estimates of the steps <= upto that have completed.  The a-priori order is a bound from the
+// 1-norm; the estimate (k_lz_scalars) uses what the recurrence has seen of the operator and typically stops 1-2 steps
+// earlier.  Every kernel of a later step evaluates this and returns at once.
+__device__ __forceinline__ int plan_steps(const ExpmPlan* p, int upto) {
+    int m = p->m;
+    if (p->apost) {
+        const unsigned t = __float_as_uint((float)p->tol);
+        for (int i = 1; i <= upto && i < m; ++i)
+            if (p->conv[i] <= t) {
+                m = i;
+                break;
+            }
+    }
+    return m;
+}
 
 enum { SPMM_PLAIN = 0, SPMM_LANCZOS = 1, SPMM_TAYLOR = 2, SPMM_AXPBY = 3 };
 
@@ -445,12 +464,12 @@ __global__ __launch_bounds__(BLK_THREADS) void k_spmm_blk(BlkDev B, int Dpad, in
 // nonzero, so one ds_read_b128 wave-instruction serves 8 nonzeros.  The b128 service groups pair lane groups
 // 0|3, 1|2, 4|7, 5|6 on the same 16 banks of a bank half; the host orders every 16-entry chunk so that the paired
 // groups read rows of opposite parity (blocking.h), which makes every read conflict-free.
-// LDS: [rowinfo 64 x int4][1792 B spare][shdot 8 x 32 x f64][rows (nun rounded up to 8) x 128 B][entries + 2 chunks].
+// LDS: [rowinfo 64 x int4][shdot 8 x 32 x f64][shdot2 8 x 32 x f64][rows (nun rounded up to 8) x 128 B][entries + 2 chunks].
 constexpr int B2_THREADS = 512;
 constexpr int B2_WAVES = B2_THREADS / WAVE;
 constexpr int B2_ROW_BYTES = 128;
 constexpr int B2_LDS_BYTES = 79872;     // == BLK2_LDS_BYTES (blocking.h)
-constexpr int B2_HEADER_BYTES = 4864;   // == BLK2_HEADER_BYTES: 1024 + 1792 + 2048
+constexpr int B2_HEADER_BYTES = 5120;   // == BLK2_HEADER_BYTES: 1024 + 2048 + 2048
 __device__ __forceinline__ void load_meta2(const BlkMeta<float>* p, unsigned (&li)[2], float (&v)[2]) {
     const uint4 a = reinterpret_cast<const uint4*>(p)[0];
     li[0] = a.x; v[0] = __uint_as_float(a.y); li[1] = a.z; v[1] = __uint_as_float(a.w);
@@ -516,7 +535,7 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(B2_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_spmm_blk2(BlkDev B, int Dpad, int ntiles, Blk2Sched sched, const T* __restrict__ val_blk, const T* __restrict__ U, T* __restrict__ Out,
                  T* __restrict__ F, const T* __restrict__ X2, double ascale, double shift, double inv_k, double* __restrict__ partial,
-                 const ExpmPlan* __restrict__ plan, int step, unsigned long long* __restrict__ stamps) {
+                 double* __restrict__ partial_o2, const ExpmPlan* __restrict__ plan, int step, unsigned long long* __restrict__ stamps) {
     constexpr int VEC = V16<T>::N;
     constexpr int CT = B2_ROW_BYTES / (int)sizeof(T);  // columns per tile
 #define MMW_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -525,15 +544,21 @@ void k_spmm_blk2(BlkDev B, int Dpad, int ntiles, Blk2Sched sched, const T* __res
         stamps[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_getreg(63492);
         stamps[(size_t)blockIdx.x * 16 + 11] = __builtin_amdgcn_s_getreg(63508);
     }
+    bool shifted = false;  // Lanczos on A - mu I with column sums of squares of the product (a-posteriori stop, k_lz_scalars)
     if (plan) {
-        if (step > plan->m) return;
+        if (MODE == SPMM_LANCZOS) {
+            if (step > plan_steps(plan, step - 1)) return;
+            shifted = plan->apost != 0 && partial_o2 != nullptr;
+            if (shifted) shift = plan->mu;
+        } else if (step > plan->m) return;
         if (MODE == SPMM_TAYLOR) shift = plan->mu / plan->nsub;
     }
     constexpr int RPP = B2_THREADS / 8;        // union rows gathered per pass
     constexpr int NG = (BLK_UNION_ROWS + RPP - 1) / RPP;   // gathers per thread
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     int4* rowinfo = reinterpret_cast<int4*>(smem_raw);                          // [64]
-    double* shdot = reinterpret_cast<double*>(smem_raw + 1024 + 1792);         // [B2_WAVES][CT]
+    double* shdot = reinterpret_cast<double*>(smem_raw + 1024);                // [B2_WAVES][CT]
+    double* shdot2 = reinterpret_cast<double*>(smem_raw + 1024 + 2048);        // [B2_WAVES][CT]
     char* tile = smem_raw + B2_HEADER_BYTES;                                   // [max(nun,2)][128 B]
     // Two-phase static schedule (Blk2Sched): whole row blocks first, one workgroup each; the blocks that would start a
     // mostly empty last round are cut into tile groups so that their pieces fill the chip.  Ids are XCD-aware within a phase.
@@ -617,9 +642,9 @@ void k_spmm_blk2(BlkDev B, int Dpad, int ntiles, Blk2Sched sched, const T* __res
         if (t + 1 < t1) gather(t + 1);  // next tile's rows fly while this tile is consumed from LDS
         const int col0 = t * CT;
         const bool colok = col0 + l8 * VEC < Dpad;
-        T dotw[VEC];  // alpha numerators of this wave's rows (lanes of group 0)
+        T dotw[VEC], dotw2[VEC];  // alpha numerators / squares of the product, this wave's rows (lanes of group 0)
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) dotw[v] = T(0);
+        for (int v = 0; v < VEC; ++v) dotw[v] = dotw2[v] = T(0);
         for (int r = wib; r < nrows; r += B2_WAVES) {
             T acc[VEC];
 #pragma unroll
@@ -695,8 +720,9 @@ void k_spmm_blk2(BlkDev B, int Dpad, int ntiles, Blk2Sched sched, const T* __res
                     load16(reinterpret_cast<const T*>(tbase + self_off), u);  // U[row] is in the staged union (diagonal entry)
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
-                        o[v] = (T)ascale * acc[v];
+                        o[v] = (T)ascale * acc[v] - (T)shift * u[v];  // shift is 0 unless the recurrence runs on A - mu I
                         dotw[v] += u[v] * o[v];  // this wave's 2-3 rows of the tile; widened once per tile below
+                        dotw2[v] += o[v] * o[v];
                     }
                 } else if (MODE == SPMM_AXPBY) {
                     T f[VEC], x2[VEC];
@@ -720,7 +746,10 @@ void k_spmm_blk2(BlkDev B, int Dpad, int ntiles, Blk2Sched sched, const T* __res
         }
         if (MODE == SPMM_LANCZOS && g == 0) {
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) shdot[wib * CT + l8 * VEC + v] = (double)dotw[v];
+            for (int v = 0; v < VEC; ++v) {
+                shdot[wib * CT + l8 * VEC + v] = (double)dotw[v];
+                shdot2[wib * CT + l8 * VEC + v] = (double)dotw2[v];
+            }
         }
         if (t == t0) MMW_STAMP(5);
         __syncthreads();  // every wave is done with this tile (and shdot is complete)
@@ -728,9 +757,13 @@ void k_spmm_blk2(BlkDev B, int Dpad, int ntiles, Blk2Sched sched, const T* __res
         if (MODE == SPMM_LANCZOS) {
             for (int c = threadIdx.x; c < CT; c += B2_THREADS)
                 if (col0 + c < Dpad) {
-                    double s = 0.0;
-                    for (int w = 0; w < B2_WAVES; ++w) s += shdot[w * CT + c];
+                    double s = 0.0, s2 = 0.0;
+                    for (int w = 0; w < B2_WAVES; ++w) {
+                        s += shdot[w * CT + c];
+                        s2 += shdot2[w * CT + c];
+                    }
                     partial[(size_t)rb * Dpad + col0 + c] = s;
+                    if (shifted) partial_o2[(size_t)rb * Dpad + col0 + c] = s2;
                 }
         }
         if (t + 1 < t1) {
@@ -825,7 +858,7 @@ __global__ __launch_bounds__(BLOCK) void k_lz_update(int K, int Dpad, int j, con
                                                      const T* __restrict__ Ujm1, T* __restrict__ Unext, LanczosScalars S,
                                                      double* __restrict__ partial, const ExpmPlan* __restrict__ plan) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    if (plan && j >= plan->m) return;  // U_{m+1} is never formed: the last product feeds the combination directly
+    if (plan && j >= plan_steps(plan, j)) return;  // U_{m+1} is never formed: the last product feeds the combination directly
     double* sh = reinterpret_cast<double*>(smem_raw);  // [BLOCK]
     const int rpp = BLOCK / Dpad > 0 ? BLOCK / Dpad : 1;
     for (int c0 = 0; c0 < Dpad; c0 += BLOCK) {
@@ -866,8 +899,11 @@ __global__ __launch_bounds__(BLOCK) void k_lz_update(int K, int Dpad, int j, con
 // with t_m = A U_m (the last SpMM's output, U_j unnormalised):
 //   coef[j] = beta0 g_j sinv_j  minus the w-terms folded onto U_m and U_{m-1};  coef[m+1] = beta0 phi sinv_m / nsub.
 // exp(M) e_1 by a scaled Taylor series on the small vector (repeated application keeps it valid for any norm).
-template <int NMAX>  // NMAX >= m + 1; all loops fully unrolled so the small vectors live in registers
-__device__ __forceinline__ void texp_core(int Dpad, int c, int m, double inv_nsub, LanczosScalars S) {
+// With `est` the matrix gets one more row, [0 .. 0 1 0]: the extra component is e_m^T phi_2(T) e_1, the leading coefficient of
+// the corrected scheme's error  beta0 beta_m sum_{k>=2} (e_m^T phi_k(T) e_1) A^{k-1} v_{m+1}  (Saad 1992, Thm 5.1); returned.
+// `scale` multiplies the result (e^{mu} when the recurrence ran on the shifted operator).
+template <int NMAX>  // NMAX >= m + 2; all loops fully unrolled so the small vectors live in registers
+__device__ __forceinline__ double texp_core(int Dpad, int c, int m, double inv_nsub, LanczosScalars S, double scale, bool est) {
     double a[NMAX], b[NMAX], g[NMAX], t[NMAX], f[NMAX];
     double nrm = 0.0;
     int mm = m;  // Krylov dimension actually reached
@@ -880,7 +916,7 @@ __device__ __forceinline__ void texp_core(int Dpad, int c, int m, double inv_nsu
     for (int j = NMAX - 1; j >= 0; --j)
         if (j + 1 < m && b[j] == 0.0) mm = j + 1;  // breakdown: the leading block is exact, no correction
     const bool corrected = mm == m && S.sinv[m * Dpad + c] != 0.0;
-    const int n = corrected ? m + 1 : mm;
+    const int n = corrected ? (est ? m + 2 : m + 1) : mm;
 #pragma unroll
     for (int j = 0; j < NMAX; ++j)
         if (j < mm) {
@@ -910,7 +946,7 @@ __device__ __forceinline__ void texp_core(int Dpad, int c, int m, double inv_nsu
                     if (j > 0) v += b[j > 0 ? j - 1 : 0] * t[j > 0 ? j - 1 : 0];
                     if (j + 1 < mm && j + 1 < NMAX) v += b[j] * t[j + 1 < NMAX ? j + 1 : j];
                 } else if (j < n) {
-                    v = t[j > 0 ? j - 1 : 0];  // the augmented row e_m^T
+                    v = t[j > 0 ? j - 1 : 0];  // the augmented rows e_m^T and e_{m+1}^T
                 }
                 tn[j] = v * isq / k;
                 big = fabs(tn[j]) > big ? fabs(tn[j]) : big;
@@ -925,12 +961,13 @@ __device__ __forceinline__ void texp_core(int Dpad, int c, int m, double inv_nsu
 #pragma unroll
         for (int j = 0; j < NMAX; ++j) g[j] = f[j];
     }
-    const double e = S.beta[c];
-    double gm = 0.0;
+    const double e = S.beta[c] * scale;
+    double gm = 0.0, gm2 = 0.0;
 #pragma unroll
     for (int j = 0; j < NMAX; ++j) {
         if (j < m) S.coef[(j + 1) * Dpad + c] = j < mm ? e * g[j] * S.sinv[(j + 1) * Dpad + c] : 0.0;
         if (j == m) gm = g[j];
+        if (j == m + 1) gm2 = g[j];
     }
     double ct = 0.0;
     if (corrected) {
@@ -941,62 +978,61 @@ __device__ __forceinline__ void texp_core(int Dpad, int c, int m, double inv_nsu
         if (m > 1) S.coef[(m - 1) * Dpad + c] -= w * S.beta[(m - 1) * Dpad + c] * S.sinv[(m - 1) * Dpad + c];
     }
     S.coef[(m + 1) * Dpad + c] = ct;
-}
-__global__ void k_lz_texp(int Dpad, int m, double inv_nsub, LanczosScalars S, const ExpmPlan* __restrict__ plan) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= Dpad) return;
-    if (plan) {
-        m = plan->m;
-        inv_nsub = 1.0 / plan->nsub;
-    }
-    if (m + 1 <= 4) texp_core<4>(Dpad, c, m, inv_nsub, S);
-    else if (m + 1 <= 8) texp_core<8>(Dpad, c, m, inv_nsub, S);
-    else texp_core<MAX_ORDER + 1>(Dpad, c, m, inv_nsub, S);
+    return corrected ? fabs(gm2) : 0.0;
 }
 // All Lanczos scalars of step j in ONE launch (fixed summation order, like k_colreduce):
 //   partB  holds the column sums of squares of U_j (j == 1: of the start block)  -> beta_{j-1}, sinv_j
 //   partA  holds the alpha numerators U_j . A U_j of the product just made        -> alpha_j
 // and, on the last step (j == m), the small exponentials (texp_core) of the columns this workgroup owns.
 constexpr int LZS_COLS = 4;  // columns per workgroup: 32-byte slab segments, 256 slab slices in flight per column
-__global__ __launch_bounds__(1024) void k_lz_scalars(int nbA, const double* __restrict__ partA, int nbB, const double* __restrict__ partB,
-                                                     int Dpad, int j, int m, double inv_nsub, double eps, LanczosScalars S,
-                                                     const ExpmPlan* __restrict__ plan) {
+__global__ __launch_bounds__(1024) void k_lz_scalars(int nbA, const double* __restrict__ partA, const double* __restrict__ partO2, int nbB,
+                                                     const double* __restrict__ partB, int Dpad, int j, int m, double inv_nsub, double eps,
+                                                     LanczosScalars S, ExpmPlan* __restrict__ plan) {
     constexpr int SL = 1024 / LZS_COLS;
-    __shared__ double shA[SL][LZS_COLS + 1], shB[SL][LZS_COLS + 1];
-    __shared__ double s2A[16][LZS_COLS + 1], s2B[16][LZS_COLS + 1];
+    __shared__ double shA[SL][LZS_COLS + 1], shB[SL][LZS_COLS + 1], shO[SL][LZS_COLS + 1];
+    __shared__ double s2A[16][LZS_COLS + 1], s2B[16][LZS_COLS + 1], s2O[16][LZS_COLS + 1];
+    bool apost = false;
+    double scale = 1.0;
     if (plan) {
-        m = plan->m;
         inv_nsub = 1.0 / plan->nsub;
-        if (j > m) return;
+        if (j > plan_steps(plan, j - 1)) return;  // beyond the a-priori order, or an earlier step already met the tolerance
+        apost = plan->apost != 0 && partO2 != nullptr;
+        if (apost) scale = exp(plan->mu * inv_nsub);  // the recurrence ran on A - mu I
     }
     const int cl = threadIdx.x % LZS_COLS, sl = threadIdx.x / LZS_COLS;
     const int c = blockIdx.x * LZS_COLS + cl;
-    double sa = 0.0, sb = 0.0;
+    double sa = 0.0, sb = 0.0, so = 0.0;
     if (c < Dpad) {
         for (int b = sl; b < nbB; b += SL) sb += partB[(size_t)b * Dpad + c];
         for (int b = sl; b < nbA; b += SL) sa += partA[(size_t)b * Dpad + c];
+        if (apost)
+            for (int b = sl; b < nbA; b += SL) so += partO2[(size_t)b * Dpad + c];
     }
     shA[sl][cl] = sa;
     shB[sl][cl] = sb;
+    shO[sl][cl] = so;
     __syncthreads();
     if (sl < 16) {  // fixed two-level order: 16 runs of SL/16 slices, then the 16 run totals
-        double ta = 0.0, tb = 0.0;
+        double ta = 0.0, tb = 0.0, to = 0.0;
         for (int p = 0; p < SL / 16; ++p) {
             ta += shA[sl * (SL / 16) + p][cl];
             tb += shB[sl * (SL / 16) + p][cl];
+            to += shO[sl * (SL / 16) + p][cl];
         }
         s2A[sl][cl] = ta;
         s2B[sl][cl] = tb;
+        s2O[sl][cl] = to;
     }
     __syncthreads();
     if (sl != 0 || c >= Dpad) return;
-    double ta = 0.0, tb = 0.0;
+    double ta = 0.0, tb = 0.0, to = 0.0;
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
         ta += s2A[p][cl];
         tb += s2B[p][cl];
+        to += s2O[p][cl];
     }
-    double si;
+    double si, bprev = 0.0;  // bprev = beta_{j-1}
     if (j == 1) {  // beta0 = ||b_c||, sinv_1
         const double b = sqrt(tb);
         si = b > 0.0 ? 1.0 / b : 0.0;
@@ -1005,30 +1041,63 @@ __global__ __launch_bounds__(1024) void k_lz_scalars(int nbA, const double* __re
     } else {  // beta_{j-1} = ||U_j||, sinv_j; a column at rounding level has exhausted its Krylov space
         const int i = j - 1;
         const double b = sqrt(tb);
-        const double scale = fabs(S.alpha[i * Dpad + c]) + (i > 1 ? S.beta[(i - 1) * Dpad + c] : 0.0);
-        const bool dead = S.sinv[i * Dpad + c] == 0.0 || !(b > eps * scale) || !(b > 0.0);
+        const double sc = fabs(S.alpha[i * Dpad + c]) + (i > 1 ? S.beta[(i - 1) * Dpad + c] : 0.0);
+        const bool dead = S.sinv[i * Dpad + c] == 0.0 || !(b > eps * sc) || !(b > 0.0);
         si = dead ? 0.0 : 1.0 / b;
-        S.beta[i * Dpad + c] = dead ? 0.0 : b;
+        bprev = dead ? 0.0 : b;
+        S.beta[i * Dpad + c] = bprev;
         S.sinv[j * Dpad + c] = si;
     }
-    S.alpha[j * Dpad + c] = si * si * ta;  // alpha_j = sinv_j^2 (U_j . A U_j)
-    if (j == m) {
-        __threadfence_block();
-        if (m + 1 <= 4) texp_core<4>(Dpad, c, m, inv_nsub, S);
-        else if (m + 1 <= 8) texp_core<8>(Dpad, c, m, inv_nsub, S);
-        else texp_core<MAX_ORDER + 1>(Dpad, c, m, inv_nsub, S);
+    const double alpha = si * si * ta;  // alpha_j = sinv_j^2 (U_j . A U_j)
+    S.alpha[j * Dpad + c] = alpha;
+    const int mlast = plan ? plan->m : m;
+    if (!apost) {
+        if (j == mlast) {
+            __threadfence_block();
+            if (j + 2 <= 4) texp_core<4>(Dpad, c, j, inv_nsub, S, scale, false);
+            else if (j + 2 <= 8) texp_core<8>(Dpad, c, j, inv_nsub, S, scale, false);
+            else texp_core<MAX_ORDER + 2>(Dpad, c, j, inv_nsub, S, scale, false);
+        }
+        return;
     }
+    // A-posteriori stop.  The combination coefficients for "stop after this step" are made at every step, together with
+    //   est = e^rho * beta_j * |e_j^T phi_2(T_j) e_1| * rho / (1 - rho)  >=  ||error|| / ||exp(A)b||   for this column,
+    // the leading term of Saad's expansion of the corrected scheme's error with ||A - mu I|| replaced by its 1-norm bound rho
+    // and the remaining terms by a geometric tail.  beta_j = ||A v_j - alpha_j v_j - beta_{j-1} v_{j-1}|| comes from the
+    // column sums of squares of the product the SpMM just made: ||A v_j||^2 = alpha_j^2 + beta_{j-1}^2 + beta_j^2.
+    __threadfence_block();
+    double phi2;
+    if (j + 2 <= 4) phi2 = texp_core<4>(Dpad, c, j, inv_nsub, S, scale, true);
+    else if (j + 2 <= 8) phi2 = texp_core<8>(Dpad, c, j, inv_nsub, S, scale, true);
+    else phi2 = texp_core<MAX_ORDER + 2>(Dpad, c, j, inv_nsub, S, scale, true);
+    const double n2 = si * si * to;
+    double bj2 = n2 - alpha * alpha - bprev * bprev;
+    const double floor2 = 4.0 * eps * n2;  // cancellation floor of the difference (the products were rounded to T)
+    if (!(bj2 > floor2)) bj2 = floor2;
+    const double rho = plan->rho;
+    const double est = si == 0.0 ? 0.0 : exp(rho) * sqrt(bj2) * phi2 * rho / (1.0 - rho);
+    float ef = (float)est;
+    if (!(ef >= 0.0f)) ef = __uint_as_float(0x7f800000u);  // NaN -> +inf: never stops early
+    if ((double)ef < est) ef = __uint_as_float(__float_as_uint(ef) + 1u);  // round up
+    atomicMax(&plan->conv[j], __float_as_uint(ef));  // a maximum: the result does not depend on the order of arrival
 }
 // y[row,:] = sum_{j=1..m} coef[j][:] * U_j[row,:] + coef[m+1][:] * Tm[row,:]   (U_j = Ubase + (j-1)*stride),
 // one wavefront per row; optionally also d[row] = ||y_row||^2 and per-block partial sums of d (the trace).
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_lz_combine(int K, int Dpad, int m, const T* __restrict__ Ubase, size_t stride,
                                                       const T* __restrict__ Tm, const double* __restrict__ coef, T* __restrict__ Yout,
-                                                      const ExpmPlan* __restrict__ plan, T* __restrict__ d,
-                                                      double* __restrict__ dpart) {
+                                                      ExpmPlan* __restrict__ plan, T* __restrict__ d,
+                                                      double* __restrict__ dpart, int* __restrict__ viol) {
     constexpr int VEC = V16<T>::N;
     __shared__ double sh[WAVES_PER_BLOCK];
-    if (plan) m = plan->m;
+    if (plan) {
+        m = plan_steps(plan, plan->m);  // the last step that ran made the coefficients for stopping there
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            plan->m_eff = m;
+            // the host launched fewer steps than the a-priori order and the estimate did not accept them either: replay
+            if (plan->apost && plan->m_apriori > plan->m && m == plan->m && plan->conv[m] > __float_as_uint((float)plan->tol) && viol) *viol = 1;
+        }
+    }
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int ngroups = Dpad / VEC;
     double tot = 0.0;
@@ -1180,7 +1249,7 @@ __host__ __device__ inline int plan_order(int method, double rho, double tol, in
 // if the matrix needs more, the sticky flag *viol is raised and the caller replays the batch synchronously.
 constexpr int PLAN_THREADS = 256;
 __global__ __launch_bounds__(PLAN_THREADS) void k_plan(int K, int method, int max_order, double tol, const double* __restrict__ part, int np,
-                                                       ExpmPlan* __restrict__ plan, int m_launch, int* __restrict__ viol) {
+                                                       ExpmPlan* __restrict__ plan, int m_launch, int* __restrict__ viol, int apost) {
     __shared__ double sh[PLAN_THREADS / WAVE];
     double tr = 0.0, pp = -1e300, pm = -1e300;
     for (int i = threadIdx.x; i < np; i += PLAN_THREADS) {
@@ -1197,8 +1266,9 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan(int K, int method, int ma
         ExpmPlan p;
         p.rho = r;
         p.mu = mu;
+        p.tol = tol;
         p.overflow = 0;
-        p.pad = 0;
+        p.m_eff = 0;
         int nsub = 1, m = -1;
         for (; nsub <= 4096; nsub *= 2) {
             m = plan_order(method, r / nsub, tol / nsub, max_order);
@@ -1210,10 +1280,16 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan(int K, int method, int ma
             p.overflow = 1;
         }
         p.m = m;
+        p.m_apriori = m;
         p.nsub = nsub;
+        // the a-posteriori stop needs the shifted recurrence of the half-tile SpMM, a single substep and a geometric tail
+        p.apost = apost && method == 0 && nsub == 1 && !p.overflow && r < 0.5;
+        for (int i = 0; i < MAX_ORDER + 2; ++i) p.conv[i] = 0u;  // identity of the maximum; a step's entry is read only after its k_lz_scalars ran
         if (m_launch > 0 && (nsub > 1 || m > m_launch || p.overflow)) {
-            *viol = 1;
-            p.m = m < m_launch ? m : m_launch;  // keep the launched kernels in range; the batch is replayed anyway
+            // more than the host launched: with the estimate on, the combination decides whether the launched steps were
+            // enough after all; without it the batch is replayed
+            if (!(p.apost && nsub == 1 && !p.overflow)) *viol = 1;
+            p.m = m < m_launch ? m : m_launch;  // keep the launched kernels in range
             p.nsub = 1;
         }
         *plan = p;

@@ -478,7 +478,7 @@ template <typename T> struct Solver final : mmw_solver {
         int viol = 0;
         MMW_TRY(eng.fetch_plan(&viol));
         if (!viol) {
-            m_guess = std::min(eng.max_order, eng.last.m + 1);
+            m_guess = std::min(eng.max_order, (eng.last.m_eff > 0 ? eng.last.m_eff : eng.last.m) + 1);
             return MMW_OK;
         }
         ++replays;
@@ -530,7 +530,7 @@ template <typename T> struct Solver final : mmw_solver {
             if (optimistic && it > 0 && it % 16 == 0) {  // cheap periodic look at the device-side order
                 int viol = 0;
                 MMW_TRY(eng.fetch_plan(&viol));
-                if (!viol) m_launch = m_guess = std::min(eng.max_order, eng.last.m + 1);
+                if (!viol) m_launch = m_guess = std::min(eng.max_order, (eng.last.m_eff > 0 ? eng.last.m_eff : eng.last.m) + 1);
             }
             const int acc = (iter + 1 < nit) ? 1 : 0;  // the last X / Y are not averaged (mmw.py:77-78,203)
             MMW_TRY(record(0));
@@ -686,7 +686,7 @@ template <typename T> struct Solver final : mmw_solver {
             case MMW_F_PHASE_US: return export_host(phase_us, out, n);
             case MMW_F_EXPM_INFO: {
                 if (n != 4) return fail(MMW_ERR_ARG, "expm info has 4 entries");
-                out[0] = eng.last.rho; out[1] = eng.last.m; out[2] = eng.last.nsub; out[3] = eng.last.mu;
+                out[0] = eng.last.rho; out[1] = eng.last.m_eff > 0 ? eng.last.m_eff : eng.last.m; out[2] = eng.last.nsub; out[3] = eng.last.mu;
                 return MMW_OK;
             }
             case MMW_F_BLOCKING: {
@@ -793,7 +793,7 @@ int expm_apply_impl(int device, int method, int max_order, double tol, int32_t K
     MMW_HIP(hipMemcpyAsync(out, d_o64.p, (size_t)K * D * sizeof(double), hipMemcpyDeviceToHost, st));
     MMW_HIP(hipStreamSynchronize(st));
     if (info) {
-        info[0] = eng.last.rho; info[1] = eng.last.m; info[2] = eng.last.nsub; info[3] = eng.last.mu;
+        info[0] = eng.last.rho; info[1] = eng.last.m_eff > 0 ? eng.last.m_eff : eng.last.m; info[2] = eng.last.nsub; info[3] = eng.last.mu;
     }
     if (kernel_us) *kernel_us = us / reps;
     return MMW_OK;

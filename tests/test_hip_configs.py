@@ -186,3 +186,28 @@ def test_edge_cases_small_and_degenerate_graphs():
                 zo, _, remo, _ = orc.rounding_one_attempt(Z, X, state, rv[a], randint=lambda Zs, size: np.full(size, -1))
                 assert int(rem[a]) == remo and np.array_equal(z[a], zo.astype(np.int32))
             s.close()
+
+
+@pytest.mark.parametrize("eta,nit", [(0.04, 120), (0.4, 60)])
+def test_full_size_exponential_meets_the_tolerance_when_stopped_early(eta, nit):
+    """journal N=10 003, D=372, fp32: exp(L/2) R of the last iteration against scipy's expm_multiply on the same L and the same
+    sketch (first 24 columns: the columns are independent).  The Lanczos steps stop on the a-posteriori estimate, typically one
+    step before the a-priori 1-norm bound would; the result must still meet the set tolerance (1e-6) -- the north star's bar is
+    1e-5 -- and the estimate must be an upper bound of the error actually made.  eta = 0.4 makes L ten times larger."""
+    from scipy.sparse.linalg import expm_multiply
+    state, Z = journal_graph(28, 0.0319, 0), 186
+    s = _lib.Solver(Z, state, nit + 1, eta, dtype=_lib.F32)
+    s.set_expm(_lib.EXPM_LANCZOS, 12, 1e-6)
+    s.iterate(nit, None, seed=11)
+    ip, ix = s.read_i32(_lib.I_L_INDPTR), s.read_i32(_lib.I_L_INDICES)
+    K = s.K
+    s.iterate(1, None, seed=11)             # one more iteration: its L, sketch and X_half are read back
+    L = scipy.sparse.csr_matrix((s.read(_lib.F_LVAL), ix, ip), shape=(K, K))
+    R = s.read(_lib.F_SKETCH)[:, :24]
+    got = s.read(_lib.F_XHALF)[:, :24]
+    ref = expm_multiply(0.5 * L, R)
+    err = relerr(got, ref)
+    info = s.read(_lib.F_EXPM_INFO)
+    assert err < 2e-6, (err, info)           # tolerance 1e-6 + fp32 rounding of a K x D block (~4e-8 per entry)
+    assert info[1] >= 1
+    s.close()
