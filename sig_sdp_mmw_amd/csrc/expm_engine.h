@@ -36,13 +36,13 @@ inline int make_layout(int D, int vec, BlockLayout& lay, std::string& err) {
 template <typename T, int MODE>
 inline int spmm_launch(hipStream_t st, int K, const BlockLayout& lay, int nblk, const int* indptr, const int* col, const T* val,
                        const T* in, T* out, T* F, const T* X2, double c1, double c2, double c3, double* partial,
-                       const ExpmPlan* plan = nullptr, int step = 0) {
+                       const ExpmPlan* plan = nullptr, int step = 0, double* partial_o2 = nullptr) {
     const size_t sh = MODE == SPMM_LANCZOS ? (size_t)WAVES_PER_BLOCK * lay.Dpad * sizeof(double) : 0;
     switch (lay.NCH) {
-        case 1: hipLaunchKernelGGL((k_spmm<T, 1, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, X2, c1, c2, c3, partial, plan, step); break;
-        case 2: hipLaunchKernelGGL((k_spmm<T, 2, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, X2, c1, c2, c3, partial, plan, step); break;
-        case 3: hipLaunchKernelGGL((k_spmm<T, 3, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, X2, c1, c2, c3, partial, plan, step); break;
-        default: hipLaunchKernelGGL((k_spmm<T, 4, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, X2, c1, c2, c3, partial, plan, step); break;
+        case 1: hipLaunchKernelGGL((k_spmm<T, 1, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, X2, c1, c2, c3, partial, plan, step, partial_o2); break;
+        case 2: hipLaunchKernelGGL((k_spmm<T, 2, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, X2, c1, c2, c3, partial, plan, step, partial_o2); break;
+        case 3: hipLaunchKernelGGL((k_spmm<T, 3, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, X2, c1, c2, c3, partial, plan, step, partial_o2); break;
+        default: hipLaunchKernelGGL((k_spmm<T, 4, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, X2, c1, c2, c3, partial, plan, step, partial_o2); break;
     }
     MMW_HIP(hipGetLastError());
     return MMW_OK;
@@ -149,8 +149,8 @@ template <typename T> struct ExpmEngine {
     double* rownorm_part = nullptr;
     bool start_colsq_ready = false;  // the producer of the start block already filled `partial` with its column sums of squares (npart_start slabs)
     int npart_start = 0;
-    // the a-posteriori stop rides on the half-tile SpMM's shifted Lanczos epilogue
-    bool apost() const { static const bool off = getenv("MMW_NO_APOST") != nullptr; return use_blk && blk.half_tile && method == MMW_EXPM_LANCZOS && !off; }
+    // the a-posteriori stop rides on the shifted Lanczos epilogue of the half-tile and of the generic SpMM (not the full-tile one)
+    bool apost() const { static const bool off = getenv("MMW_NO_APOST") != nullptr; return (!use_blk || blk.half_tile) && method == MMW_EXPM_LANCZOS && !off; }
     int kbegin(int slot) { return kt ? kt->begin(slot) : MMW_OK; }
     int kend() { return kt ? kt->end() : MMW_OK; }
 
@@ -224,7 +224,8 @@ template <typename T> struct ExpmEngine {
             MMW_TRY((spmm_blk_launch<T, MODE>(st, blk, lay.Dpad, val_blk, in, out, F, nullptr, ascale, shift, inv_k, partial.p, plan, step,
                                               apost() ? partial_o2.p : nullptr)));
         else
-            MMW_TRY((spmm_launch<T, MODE>(st, K, lay, nblk, indptr, col, val, in, out, F, nullptr, ascale, shift, inv_k, partial.p, plan, step)));
+            MMW_TRY((spmm_launch<T, MODE>(st, K, lay, nblk, indptr, col, val, in, out, F, nullptr, ascale, shift, inv_k, partial.p, plan, step,
+                                          apost() ? partial_o2.p : nullptr)));
         return kend();
     }
     int enable_blocking(const BlkDev& b, const T* values_blocked) {

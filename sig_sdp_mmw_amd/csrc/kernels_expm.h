@@ -57,10 +57,16 @@ __global__ __launch_bounds__(BLOCK) void k_spmm(int K, BlockLayout lay, const in
                                                 const int* __restrict__ col, const T* __restrict__ val,
                                                 const T* __restrict__ U, T* __restrict__ Out, T* __restrict__ F,
                                                 const T* __restrict__ X2, double ascale, double shift, double inv_k,
-                                                double* __restrict__ partial, const ExpmPlan* __restrict__ plan, int step) {
+                                                double* __restrict__ partial, const ExpmPlan* __restrict__ plan, int step,
+                                                double* __restrict__ partial_o2) {
     constexpr int VEC = V16<T>::N;
+    bool shifted = false;  // Lanczos on A - mu I with column sums of squares of the product (a-posteriori stop, k_lz_scalars)
     if (plan) {  // device-side order: steps beyond the planned Krylov order are no-ops
-        if (step > plan->m) return;
+        if (MODE == SPMM_LANCZOS) {
+            if (step > plan_steps(plan, step - 1)) return;
+            shifted = plan->apost != 0 && partial_o2 != nullptr;
+            if (shifted) shift = plan->mu;
+        } else if (step > plan->m) return;
         if (MODE == SPMM_TAYLOR) shift = plan->mu / plan->nsub;
     }
     const int lane = threadIdx.x & 63;
@@ -69,11 +75,11 @@ __global__ __launch_bounds__(BLOCK) void k_spmm(int K, BlockLayout lay, const in
     const int g = (NCH == 1) ? lane / LPR : 0;
     const int lig = (NCH == 1) ? lane - g * LPR : lane;
     const bool active = g < G;
-    double dot[NCH][VEC];
+    double dot[NCH][VEC], dot2[NCH][VEC];
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) dot[c][v] = 0.0;
+        for (int v = 0; v < VEC; ++v) dot[c][v] = dot2[c][v] = 0.0;
 
     for (int row = blockIdx.x * WAVES_PER_BLOCK + wib; row < K; row += gridDim.x * WAVES_PER_BLOCK) {
         T acc[NCH][VEC];
@@ -139,8 +145,9 @@ __global__ __launch_bounds__(BLOCK) void k_spmm(int K, BlockLayout lay, const in
                         load16(U + off, u);
 #pragma unroll
                         for (int v = 0; v < VEC; ++v) {
-                            o[v] = (T)(ascale * (double)acc[c][v]);
+                            o[v] = (T)(ascale * (double)acc[c][v] - (MODE == SPMM_LANCZOS ? shift : 0.0) * (double)u[v]);
                             dot[c][v] += (double)u[v] * (double)o[v];
+                            dot2[c][v] += (double)o[v] * (double)o[v];
                         }
                     } else if (MODE == SPMM_AXPBY) {
                         T f[VEC], x2[VEC];
@@ -180,6 +187,22 @@ __global__ __launch_bounds__(BLOCK) void k_spmm(int K, BlockLayout lay, const in
             double s = 0.0;
             for (int w = 0; w < WAVES_PER_BLOCK; ++w) s += sh[w * Dpad + c];
             partial[(size_t)blockIdx.x * Dpad + c] = s;
+        }
+        if (shifted) {  // second slab: column sums of squares of the product
+            __syncthreads();
+            if (g == 0) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+                    if (lig + 64 * c < LPR)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) sh[wib * Dpad + (lig + 64 * c) * VEC + v] = dot2[c][v];
+            }
+            __syncthreads();
+            for (int c = threadIdx.x; c < Dpad; c += BLOCK) {
+                double s = 0.0;
+                for (int w = 0; w < WAVES_PER_BLOCK; ++w) s += sh[w * Dpad + c];
+                partial_o2[(size_t)blockIdx.x * Dpad + c] = s;
+            }
         }
     }
 }
