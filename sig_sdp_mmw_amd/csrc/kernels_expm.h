@@ -1003,6 +1003,33 @@ __device__ __forceinline__ double texp_core(int Dpad, int c, int m, double inv_n
     S.coef[(m + 1) * Dpad + c] = ct;
     return corrected ? fabs(gm2) : 0.0;
 }
+// m == 1 in closed form (the common case once the steps stop on the estimate): T is the scalar alpha, so
+// exp(T) e_1 = e^alpha, e_1^T phi_1 e_1 = (e^alpha - 1)/alpha, e_1^T phi_2 e_1 = (e^alpha - 1 - alpha)/alpha^2.  Same outputs as texp_core.
+__device__ __forceinline__ double texp_order1(int Dpad, int c, double inv_nsub, LanczosScalars S, double scale) {
+    const double si = S.sinv[1 * Dpad + c];
+    const double a = S.alpha[1 * Dpad + c] * inv_nsub;
+    const double e = S.beta[c] * scale;
+    const double g = exp(a);
+    double phi1, phi2;
+    if (fabs(a) < 1e-2) {  // series: the closed forms cancel
+        phi1 = 1.0 + a * (0.5 + a * (1.0 / 6.0 + a * (1.0 / 24.0 + a * (1.0 / 120.0 + a * (1.0 / 720.0)))));
+        phi2 = 0.5 + a * (1.0 / 6.0 + a * (1.0 / 24.0 + a * (1.0 / 120.0 + a * (1.0 / 720.0 + a * (1.0 / 5040.0)))));
+    } else {
+        const double em1 = expm1(a);
+        phi1 = em1 / a;
+        phi2 = (em1 - a) / (a * a);
+    }
+    if (si == 0.0) {  // empty column
+        S.coef[1 * Dpad + c] = 0.0;
+        S.coef[2 * Dpad + c] = 0.0;
+        return 0.0;
+    }
+    const double w = e * phi1 * inv_nsub;  // weight of w = s1*t1 - alpha1 s1 U1
+    S.coef[1 * Dpad + c] = e * g * si - w * S.alpha[1 * Dpad + c] * si;
+    S.coef[2 * Dpad + c] = w * si;
+    return fabs(phi2);
+}
+
 // All Lanczos scalars of step j in ONE launch (fixed summation order, like k_colreduce):
 //   partB  holds the column sums of squares of U_j (j == 1: of the start block)  -> beta_{j-1}, sinv_j
 //   partA  holds the alpha numerators U_j . A U_j of the product just made        -> alpha_j
@@ -1090,7 +1117,8 @@ __global__ __launch_bounds__(1024) void k_lz_scalars(int nbA, const double* __re
     // column sums of squares of the product the SpMM just made: ||A v_j||^2 = alpha_j^2 + beta_{j-1}^2 + beta_j^2.
     __threadfence_block();
     double phi2;
-    if (j + 2 <= 4) phi2 = texp_core<4>(Dpad, c, j, inv_nsub, S, scale, true);
+    if (j == 1) phi2 = texp_order1(Dpad, c, inv_nsub, S, scale);
+    else if (j + 2 <= 4) phi2 = texp_core<4>(Dpad, c, j, inv_nsub, S, scale, true);
     else if (j + 2 <= 8) phi2 = texp_core<8>(Dpad, c, j, inv_nsub, S, scale, true);
     else phi2 = texp_core<MAX_ORDER + 2>(Dpad, c, j, inv_nsub, S, scale, true);
     const double n2 = si * si * to;
