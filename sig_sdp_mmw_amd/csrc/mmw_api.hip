@@ -478,7 +478,7 @@ template <typename T> struct Solver final : mmw_solver {
         int viol = 0;
         MMW_TRY(eng.fetch_plan(&viol));
         if (!viol) {
-            m_guess = std::min(eng.max_order, (eng.last.m_eff > 0 ? eng.last.m_eff : eng.last.m) + 1);
+            m_guess = next_launch_order();
             return MMW_OK;
         }
         ++replays;
@@ -499,13 +499,37 @@ template <typename T> struct Solver final : mmw_solver {
         MMW_TRY(settle());
         if (iter + n > nit) return fail(MMW_ERR_STATE, "mmw_iterate: more iterations than announced to mmw_create/mmw_reset");
         const bool optimistic = randv == nullptr && n > 1 && !kt.on && !getenv("MMW_SYNC_PLAN");  // profiling counts exact launches
-        if (optimistic) {
+        if (!optimistic) return iterate_impl(n, randv, seed, false);
+        // Chunks enqueued without plan readbacks.  Each chunk starts from a device snapshot; before the next one starts the
+        // plan of the previous is looked at (one sync): a chunk that needed more steps than were launched is restored and
+        // replayed with per-iteration readback, and the launch order follows the device.  The last chunk is settled by the
+        // next call.  Chunks are short while L still grows fast (its norm is proportional to the iteration count).
+        int left = n;
+        while (left > 0) {
+            MMW_TRY(settle());
+            const int chunk = std::min(left, std::max(4, std::min(32, (int)iter / 2)));
             MMW_TRY(copy_state(true));
-            pend_iter0 = iter; pend_n = n; pend_seed = seed;
+            pend_iter0 = iter; pend_n = chunk; pend_seed = seed;
+            MMW_TRY(iterate_impl(chunk, nullptr, seed, chunk > 1));
+            pending = chunk > 1;
+            left -= chunk;
         }
-        MMW_TRY(iterate_impl(n, randv, seed, optimistic));
-        pending = optimistic;
         return MMW_OK;
+    }
+    // Steps to launch without reading the plan back: what the last application used, plus one spare step unless its
+    // estimate met the tolerance with a factor 8 to spare (L grows by a fraction of itself per iteration; the plan is looked
+    // at every 16 iterations; a batch that needs more anyway is replayed from its snapshot).
+    int next_launch_order() const {
+        const ExpmPlan& p = eng.last;
+        if (p.m_eff <= 0) return std::min(eng.max_order, p.m + 1);
+        int spare = 1;
+        if (p.apost && p.m_eff >= 1 && p.m_eff <= MAX_ORDER) {
+            union { unsigned u; float f; } e;
+            e.u = p.conv[p.m_eff];
+            if ((double)e.f <= p.tol / 8.0) spare = 0;
+        }
+        if (p.m_eff >= p.m_apriori) spare = 0;  // the a-priori order is never exceeded
+        return std::min(eng.max_order, p.m_eff + spare);
     }
     int sketch_slabs() const { static const int cap = getenv("MMW_SK_SLABS") ? atoi(getenv("MMW_SK_SLABS")) : 256; return std::min(grid_rows(K), cap); }  // few slabs for the start-norm reduction
     int launch_sketch(hipStream_t s, uint64_t seed, uint32_t it) {
@@ -527,11 +551,6 @@ template <typename T> struct Solver final : mmw_solver {
         const bool fuse_sketch = !kt.on && !timing && !getenv("MMW_NO_FUSED_SKETCH");  // profiling keeps the kernels apart
         sketch_done_for = -1;  // whatever an earlier batch left in the start block is not trusted
         for (int it = 0; it < n; ++it) {
-            if (optimistic && it > 0 && it % 16 == 0) {  // cheap periodic look at the device-side order
-                int viol = 0;
-                MMW_TRY(eng.fetch_plan(&viol));
-                if (!viol) m_launch = m_guess = std::min(eng.max_order, (eng.last.m_eff > 0 ? eng.last.m_eff : eng.last.m) + 1);
-            }
             const int acc = (iter + 1 < nit) ? 1 : 0;  // the last X / Y are not averaged (mmw.py:77-78,203)
             MMW_TRY(record(0));
             // ---- DUAL
