@@ -158,7 +158,8 @@ __global__ __launch_bounds__(BLOCK) void k_hweights(int K, const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_loss(PatternDev<T> P, const int* __restrict__ lrow, const T* __restrict__ Y,
                                                 const T* __restrict__ wH, const double* __restrict__ scal, T* __restrict__ lval,
-                                                double eta, const int* __restrict__ bpos, T* __restrict__ lval_blk) {
+                                                double eta, const int* __restrict__ bpos, T* __restrict__ lval_blk,
+                                                const T* __restrict__ xval = nullptr, T* __restrict__ xavg = nullptr) {
     const int K = P.K, Z = P.Z, baseF = K;
     const double invK = 1.0 / (double)K, Zm1 = (double)(Z - 1);
     const double cF = 0.5 + 1.0 / ((double)K * Zm1);
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(BLOCK) void k_loss(PatternDev<T> P, const int* __re
         const T nv = (T)((double)lval[e] - eta * add);
         lval[e] = nv;
         if (bpos) lval_blk[bpos[e]] = nv;  // the same value in the LDS-staged kernel's traversal order
+        if (xavg) xavg[e] += xval[e];  // the previous iteration's X joins the running sum here (same index space, one pass fewer)
     }
 }
 

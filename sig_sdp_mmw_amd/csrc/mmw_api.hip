@@ -548,6 +548,7 @@ template <typename T> struct Solver final : mmw_solver {
         const int gl = (int)std::min<size_t>(((size_t)H.nnzL() + BLOCK - 1) / BLOCK, (size_t)LOSS_GRID_MAX);  // LOSS: one thread per stored entry
         const int Dpad = eng.lay.Dpad;
         int m_launch = optimistic ? m_guess : 0;
+        bool xavg_deferred = false;
         const bool fuse_sketch = !kt.on && !timing && !getenv("MMW_NO_FUSED_SKETCH");  // profiling keeps the kernels apart
         sketch_done_for = -1;  // whatever an earlier batch left in the start block is not trusted
         for (int it = 0; it < n; ++it) {
@@ -563,8 +564,11 @@ template <typename T> struct Solver final : mmw_solver {
             MMW_TRY(record(1));
             // ---- LOSS
             MMW_TRY(kt.begin(KT_LOSS));
+            // the X of the previous iteration of this chunk is added to the running sum inside this pass (xavg_deferred)
             hipLaunchKernelGGL((k_loss<T>), dim3(gl), dim3(BLOCK), 0, st, P, d_lrow.p, Y.p, wH.p, scal.p, lval.p, eta,
-                               (const int*)(eng.use_blk ? b_bpos.p : nullptr), lval_blk.p);
+                               (const int*)(eng.use_blk ? b_bpos.p : nullptr), lval_blk.p, (const T*)(xavg_deferred ? xval.p : nullptr),
+                               xavg_deferred ? xavg.p : (T*)nullptr);
+            xavg_deferred = false;
             MMW_TRY(kt.end());
             MMW_TRY(record(2));
             // ---- EXPM + X on the pattern
@@ -634,7 +638,8 @@ template <typename T> struct Solver final : mmw_solver {
                 default: hipLaunchKernelGGL((k_sddmm<T, 4>), dim3(gr), dim3(BLOCK), 0, st, P, Dpad, eng.lay.LPR, eng.lay.G, Xh.p, drow.p, tr_part.p, gr, xval.p, xavg.p, acc); break;
             }
             // the running sum of X (mmw.py:77-78): one coalesced pass; none of the SDDMM kernels read-modify-writes xavg
-            if (acc) hipLaunchKernelGGL((k_accumulate<T>), dim3((unsigned)std::min<size_t>(((size_t)H.nnzL() + BLOCK - 1) / BLOCK, 4096)), dim3(BLOCK), 0, st, (size_t)H.nnzL(), xval.p, xavg.p);
+            if (acc && it + 1 < n && !kt.on) xavg_deferred = true;  // the next iteration's LOSS pass adds it
+            else if (acc) hipLaunchKernelGGL((k_accumulate<T>), dim3((unsigned)std::min<size_t>(((size_t)H.nnzL() + BLOCK - 1) / BLOCK, 4096)), dim3(BLOCK), 0, st, (size_t)H.nnzL(), xval.p, xavg.p);
             MMW_TRY(kt.end());
             MMW_HIP(hipGetLastError());
             MMW_TRY(record(3));
