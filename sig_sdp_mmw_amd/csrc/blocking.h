@@ -115,7 +115,7 @@ inline std::vector<int32_t> rcm_order(int K, const std::vector<int32_t>& indptr,
 constexpr int BLK2_LDS_BYTES = 79872;
 constexpr int BLK2_HEADER_BYTES = 5120;
 constexpr int BLK2_ROW_BYTES = 128;
-constexpr int SD2_THREADS = 512;     // workgroup size of the half-tile SDDMM
+constexpr int SD2_THREADS = 1024;    // workgroup size of the half-tile SDDMM
 struct BlockingLimits {
     int max_entries_per_block;  // staged entries of the full-tile kernel
     int entry_bytes;            // sizeof one staged entry (offset + value)

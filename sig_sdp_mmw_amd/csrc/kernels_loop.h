@@ -451,8 +451,8 @@ struct Sd2Dev {
     const int* items;          // [nitems][3] {row block, first round, end round}
     int nitems;
 };
-// the next iteration's sketch rides in the SDDMM launch as extra workgroups (the SDDMM is a latency chain that leaves the
-// VALU idle; the Philox / Box-Muller work is pure VALU): nblocks == 0 disables it
+// the next iteration's sketch can ride in the SDDMM launch as extra workgroups (MMW_FUSED_SKETCH=1; the SDDMM leaves VALU
+// time idle and the Philox / Box-Muller work is pure VALU): nblocks == 0 disables it
 template <typename T> struct SketchArgs {
     int nblocks, K, D;
     uint64_t seed;
@@ -463,15 +463,17 @@ template <typename T> struct SketchArgs {
 template <typename T, int NWAVES>
 __device__ __forceinline__ void sketch_rows(int K, int D, int Dpad, uint64_t seed, uint32_t iter, T* __restrict__ R,
                                             double* __restrict__ colsq_part, int bid, int nblocks, double* shc);
-constexpr int SD2_ROUNDS = 4;  // rounds per work item (the host cuts longer blocks into several items)
+template <typename T> constexpr int sd2_rounds() { return 4; }  // rounds per work item: the host cuts longer blocks into several items (64 VGPRs)
 template <typename T>
-__global__ __launch_bounds__(SD2_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6)))  // <= 80 VGPRs: three workgroups per CU
+// float: <= 64 VGPRs, two 16-wave workgroups per CU; double: 128 VGPRs, one workgroup per CU (it would spill at 64)
+__global__ __launch_bounds__(SD2_THREADS, sizeof(T) == 4 ? 8 : 4)
 void k_sddmm_blk2(BlkDev B, Sd2Dev S, PatternDev<T> P, int Dpad, int ntiles,
                                                             const T* __restrict__ Yb, const T* __restrict__ d,
                                                             const double* __restrict__ tr_part, int ntr, T* __restrict__ xval,
                                                             T* __restrict__ xavg, int accumulate, SketchArgs<T> sk, unsigned long long* __restrict__ stamps) {
     constexpr int VEC = V16<T>::N;
     constexpr int CT = B2_ROW_BYTES / (int)sizeof(T);
+    constexpr int SD2_ROUNDS = sd2_rounds<T>();
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     {
         const int grid_sd = (S.nitems + 7) / 8 * 8;

@@ -209,14 +209,14 @@ template <typename T> struct Solver final : mmw_solver {
                 // (each half stages the union again).
                 int cus = 256;
                 (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-                const int per_cu = std::max(1, std::min(3, 163840 / std::max(1, HB.un8_max * B2_ROW_BYTES + 128)));
+                const int per_cu = std::max(1, std::min(2048 / SD2_THREADS, 163840 / std::max(1, HB.un8_max * B2_ROW_BYTES + 128)));
                 const size_t slots = (size_t)per_cu * (size_t)cus;
                 struct It { int rb, k0, k1; };
                 auto len = [](const It& a) { return a.k1 - a.k0; };
                 auto less = [&](const It& a, const It& b) { return len(a) != len(b) ? len(a) < len(b) : a.rb > b.rb; };
                 std::priority_queue<It, std::vector<It>, decltype(less)> pq(less);
                 for (int b = 0; b < HB.nb(); ++b) pq.push({b, 0, (HB.sd2_ptr[b + 1] - HB.sd2_ptr[b]) / SD2_THREADS});
-                while ((pq.size() < slots && len(pq.top()) >= 2) || len(pq.top()) > SD2_ROUNDS) {
+                while ((pq.size() < slots && len(pq.top()) >= 2) || len(pq.top()) > sd2_rounds<T>()) {
                     const It t = pq.top();
                     pq.pop();
                     const int mid = t.k0 + (len(t) + 1) / 2;
@@ -232,7 +232,7 @@ template <typename T> struct Solver final : mmw_solver {
                 MMW_TRY(b_sd2items.upload(items, st));
             }
             MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sddmm_blk2<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        HB.un8_max * B2_ROW_BYTES));
+                                        std::max(HB.un8_max * B2_ROW_BYTES, 65536)));
             sddmm_blk2 = true;
         }
         MMW_HIP(hipStreamSynchronize(st));
@@ -549,7 +549,9 @@ template <typename T> struct Solver final : mmw_solver {
         const int Dpad = eng.lay.Dpad;
         int m_launch = optimistic ? m_guess : 0;
         bool xavg_deferred = false;
-        const bool fuse_sketch = !kt.on && !timing && !getenv("MMW_NO_FUSED_SKETCH");  // profiling keeps the kernels apart
+        // drawing the next sketch in extra workgroups of the SDDMM launch paid off with 8-wave SDDMM workgroups (+3.7 %); with
+        // 16-wave ones (two per CU, every wave slot taken) it costs 1.5 %, so it is opt-in
+        const bool fuse_sketch = !kt.on && !timing && getenv("MMW_FUSED_SKETCH") != nullptr;
         sketch_done_for = -1;  // whatever an earlier batch left in the start block is not trusted
         for (int it = 0; it < n; ++it) {
             const int acc = (iter + 1 < nit) ? 1 : 0;  // the last X / Y are not averaged (mmw.py:77-78,203)
@@ -607,17 +609,18 @@ template <typename T> struct Solver final : mmw_solver {
                 constexpr int CT2 = B2_ROW_BYTES / (int)sizeof(T);
                 const int per = (sd2_nitems + 7) / 8;
                 SketchArgs<T> sk{};
-                const size_t sd_lds = (size_t)HB.un8_max * B2_ROW_BYTES;
+                const size_t sd_lds = std::max((size_t)HB.un8_max * B2_ROW_BYTES, std::min((size_t)(SD2_THREADS / WAVE) * Dpad * sizeof(double), (size_t)65536));
                 const bool lzm = eng.method == MMW_EXPM_LANCZOS;
                 if (fuse_sketch && !randv && it + 1 < n && (size_t)(SD2_THREADS / WAVE) * Dpad * sizeof(double) <= sd_lds) {
                     // the start block and its norm slabs are free once the combination has run: draw the next iteration's sketch here
-                    sk.nblocks = (sketch_slabs() + 1) / 2;  // 8-wave workgroups, each standing for two of the stand-alone kernel's
+                    constexpr int VBW = SD2_THREADS / BLOCK;  // a workgroup here stands for this many of the stand-alone kernel's
+                    sk.nblocks = (sketch_slabs() + VBW - 1) / VBW;
                     sk.K = K; sk.D = D; sk.seed = seed; sk.iter = (uint32_t)(iter + 1);
                     sk.R = eng.start_block();
                     sk.colsq_part = lzm ? eng.partial_sq.p : nullptr;
                     sketch_done_for = (int64_t)iter + 1;
                     sketch_done_seed = seed;
-                    sketch_done_slabs = sk.nblocks * 2;
+                    sketch_done_slabs = sk.nblocks * VBW;
                 }
                 hipLaunchKernelGGL((k_sddmm_blk2<T>), dim3(per * 8 + sk.nblocks), dim3(SD2_THREADS), sd_lds, st, blkdev(), S, P, Dpad,
                                    (Dpad + CT2 - 1) / CT2, Xh.p, drow.p, tr_part.p, gr, xval.p, xavg.p, acc, sk, sd_stamps);
