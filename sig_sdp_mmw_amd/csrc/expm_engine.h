@@ -150,7 +150,8 @@ template <typename T> struct ExpmEngine {
     bool start_colsq_ready = false;  // the producer of the start block already filled `partial` with its column sums of squares (npart_start slabs)
     int npart_start = 0;
     // the a-posteriori stop rides on the shifted Lanczos epilogue of the half-tile and of the generic SpMM (not the full-tile one)
-    bool apost() const { static const bool off = getenv("MMW_NO_APOST") != nullptr; return (!use_blk || blk.half_tile) && method == MMW_EXPM_LANCZOS && !off; }
+    bool apost_off = getenv("MMW_NO_APOST") != nullptr;  // read when the handle is created
+    bool apost() const { return (!use_blk || blk.half_tile) && method == MMW_EXPM_LANCZOS && !apost_off; }
     int kbegin(int slot) { return kt ? kt->begin(slot) : MMW_OK; }
     int kend() { return kt ? kt->end() : MMW_OK; }
 

@@ -70,6 +70,7 @@ template <typename T> struct Solver final : mmw_solver {
     DevBuf<T> sn_lval, sn_lblk, sn_xval, sn_xavg, sn_Y, sn_yavg, sn_eaccu;
     bool pending = false;
     int pend_iter0 = 0, pend_n = 0, m_guess = 3;
+    size_t pend_events0 = 0;  // phase-timer events recorded before the pending chunk
     uint64_t pend_seed = 0;
     int replays = 0;
     ExpmEngine<T> eng;
@@ -485,10 +486,10 @@ template <typename T> struct Solver final : mmw_solver {
         MMW_TRY(eng.clear_violation());
         MMW_TRY(copy_state(false));
         iter = pend_iter0;
-        if (timing) {  // drop the timers of the discarded batch
+        if (timing) {  // drop the timers of the discarded chunk (earlier chunks keep theirs)
             MMW_HIP(hipStreamSynchronize(st));
-            for (auto e : events) (void)hipEventDestroy(e);
-            events.clear();
+            for (size_t i = pend_events0; i < events.size(); ++i) (void)hipEventDestroy(events[i]);
+            events.resize(std::min(events.size(), pend_events0));
         }
         return iterate_impl(pend_n, nullptr, pend_seed, false);
     }
@@ -509,7 +510,7 @@ template <typename T> struct Solver final : mmw_solver {
             MMW_TRY(settle());
             const int chunk = std::min(left, std::max(4, std::min(32, (int)iter / 2)));
             MMW_TRY(copy_state(true));
-            pend_iter0 = iter; pend_n = chunk; pend_seed = seed;
+            pend_iter0 = iter; pend_n = chunk; pend_seed = seed; pend_events0 = events.size();
             MMW_TRY(iterate_impl(chunk, nullptr, seed, chunk > 1));
             pending = chunk > 1;
             left -= chunk;

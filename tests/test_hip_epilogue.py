@@ -146,3 +146,21 @@ def test_binary_search_end_to_end_on_device():
             if mem.size:
                 assert np.all(Sd[np.ix_(mem, mem)].sum(axis=0) <= h[mem] + 1e-12)
                 assert Q[np.ix_(mem, mem)].nnz == 0
+
+
+def test_replayed_chunks_keep_the_phase_timers_consistent(monkeypatch):
+    """Without the a-posteriori stop the a-priori order rises during the run, chunks enqueued with too few stages are
+    restored and replayed, and the per-iteration phase timers (one row per iteration, like the reference's log) must still
+    come out one row per iteration."""
+    from sig_sdp_mmw_amd.graphs import journal_graph
+    monkeypatch.setenv("MMW_NO_APOST", "1")
+    state = journal_graph(8, 75e-4, seed=1)  # K = 192
+    s = _lib.Solver(12, state, 40, 0.05, dtype=_lib.F32)
+    s.set_timing(True)
+    s.iterate(40, None, seed=3)
+    s.sync()
+    t = s.read(_lib.F_PHASE_US).reshape(40, 4)
+    assert np.all(t > 0)
+    info = s.read(_lib.F_BLOCKING)
+    assert info[3] >= 1, "this configuration is expected to replay at least one chunk"
+    s.close()
