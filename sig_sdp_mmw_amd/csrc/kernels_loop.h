@@ -28,6 +28,20 @@ template <typename T> struct PatternDev {
     const T* cH;          // h_max/K - S_sum/(K Z)
 };
 
+// The sketch of an iteration is pure VALU work that depends on nothing but (seed, iteration): it rides as extra workgroups in
+// the launch of a memory-latency-bound kernel -- the LOSS pass of the same iteration (default), or the SDDMM of the previous
+// one (MMW_FUSED_SKETCH=1).  nblocks == 0 disables it.
+template <typename T> struct SketchArgs {
+    int nblocks, K, D;
+    uint64_t seed;
+    uint32_t iter;
+    T* R;
+    double* colsq_part;
+};
+template <typename T, int NWAVES>
+__device__ __forceinline__ void sketch_rows(int K, int D, int Dpad, uint64_t seed, uint32_t iter, T* __restrict__ R,
+                                            double* __restrict__ colsq_part, int bid, int nblocks, double* shc);
+
 // ---- DUAL, step 1: per row r[k] = sum of off-diagonal X, eD; per pair eF -------------------------
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_dual_rows(PatternDev<T> P, const T* __restrict__ xval, T* __restrict__ rsum,
@@ -159,14 +173,22 @@ template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_loss(PatternDev<T> P, const int* __restrict__ lrow, const T* __restrict__ Y,
                                                 const T* __restrict__ wH, const double* __restrict__ scal, T* __restrict__ lval,
                                                 double eta, const int* __restrict__ bpos, T* __restrict__ lval_blk,
-                                                const T* __restrict__ xval = nullptr, T* __restrict__ xavg = nullptr) {
+                                                const T* __restrict__ xval = nullptr, T* __restrict__ xavg = nullptr,
+                                                SketchArgs<T> sk = SketchArgs<T>{}, int Dpad = 0) {
+    if ((int)blockIdx.x < sk.nblocks) {  // leading workgroups draw this iteration's sketch (same shape as k_sketch_rng: same bits)
+        extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+        sketch_rows<T, WAVES_PER_BLOCK>(sk.K, sk.D, Dpad, sk.seed, sk.iter, sk.R, sk.colsq_part, (int)blockIdx.x, sk.nblocks,
+                                        reinterpret_cast<double*>(smem_raw));
+        return;
+    }
+    const int bid = (int)blockIdx.x - sk.nblocks, nb = (int)gridDim.x - sk.nblocks;
     const int K = P.K, Z = P.Z, baseF = K;
     const double invK = 1.0 / (double)K, Zm1 = (double)(Z - 1);
     const double cF = 0.5 + 1.0 / ((double)K * Zm1);
     const double sumYD = scal[0], sumYF = scal[1], sumW = scal[2];
     const double dconst = -(sumYD * invK) / (1.0 - invK) + (sumYF / ((double)K * Zm1)) / cF - sumW;
     const double gscale = Zm1 / (double)(2 * Z);
-    for (int e = blockIdx.x * BLOCK + threadIdx.x; e < P.nnzL; e += gridDim.x * BLOCK) {
+    for (int e = bid * BLOCK + threadIdx.x; e < P.nnzL; e += nb * BLOCK) {
         const int row = lrow[e], c = P.col[e];
         double add;
         if (c == row) {
@@ -451,18 +473,6 @@ struct Sd2Dev {
     const int* items;          // [nitems][3] {row block, first round, end round}
     int nitems;
 };
-// the next iteration's sketch can ride in the SDDMM launch as extra workgroups (MMW_FUSED_SKETCH=1; the SDDMM leaves VALU
-// time idle and the Philox / Box-Muller work is pure VALU): nblocks == 0 disables it
-template <typename T> struct SketchArgs {
-    int nblocks, K, D;
-    uint64_t seed;
-    uint32_t iter;
-    T* R;
-    double* colsq_part;
-};
-template <typename T, int NWAVES>
-__device__ __forceinline__ void sketch_rows(int K, int D, int Dpad, uint64_t seed, uint32_t iter, T* __restrict__ R,
-                                            double* __restrict__ colsq_part, int bid, int nblocks, double* shc);
 template <typename T> constexpr int sd2_rounds() { return 4; }  // rounds per work item: the host cuts longer blocks into several items (64 VGPRs)
 template <typename T>
 // float: <= 64 VGPRs, two 16-wave workgroups per CU; double: 128 VGPRs, one workgroup per CU (it would spill at 64)

@@ -567,10 +567,20 @@ template <typename T> struct Solver final : mmw_solver {
             MMW_TRY(record(1));
             // ---- LOSS
             MMW_TRY(kt.begin(KT_LOSS));
-            // the X of the previous iteration of this chunk is added to the running sum inside this pass (xavg_deferred)
-            hipLaunchKernelGGL((k_loss<T>), dim3(gl), dim3(BLOCK), 0, st, P, d_lrow.p, Y.p, wH.p, scal.p, lval.p, eta,
-                               (const int*)(eng.use_blk ? b_bpos.p : nullptr), lval_blk.p, (const T*)(xavg_deferred ? xval.p : nullptr),
-                               xavg_deferred ? xavg.p : (T*)nullptr);
+            // the X of the previous iteration of this chunk is added to the running sum inside this pass (xavg_deferred), and
+            // this iteration's sketch is drawn by leading workgroups of the same launch (VALU work under a memory-bound pass)
+            SketchArgs<T> skl{};
+            const bool lz_m = eng.method == MMW_EXPM_LANCZOS;
+            const bool sketch_have = !randv && sketch_done_for == (int64_t)iter && sketch_done_seed == seed;
+            if (!randv && !sketch_have && !kt.on && !timing && !getenv("MMW_NO_LOSS_SKETCH")) {
+                skl.nblocks = sketch_slabs(); skl.K = K; skl.D = D; skl.seed = seed; skl.iter = (uint32_t)iter;
+                skl.R = eng.start_block();
+                skl.colsq_part = lz_m ? eng.partial_sq.p : nullptr;
+                sketch_done_for = (int64_t)iter; sketch_done_seed = seed; sketch_done_slabs = skl.nblocks;
+            }
+            hipLaunchKernelGGL((k_loss<T>), dim3(gl + skl.nblocks), dim3(BLOCK), skl.nblocks && lz_m ? (size_t)WAVES_PER_BLOCK * Dpad * sizeof(double) : 0,
+                               st, P, d_lrow.p, Y.p, wH.p, scal.p, lval.p, eta, (const int*)(eng.use_blk ? b_bpos.p : nullptr), lval_blk.p,
+                               (const T*)(xavg_deferred ? xval.p : nullptr), xavg_deferred ? xavg.p : (T*)nullptr, skl, Dpad);
             xavg_deferred = false;
             MMW_TRY(kt.end());
             MMW_TRY(record(2));
