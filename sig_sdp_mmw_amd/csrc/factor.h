@@ -73,6 +73,7 @@ template <typename T> struct DenseWork {
     hipStream_t st = nullptr;
     DevBuf<double> G, Q, Q2, G2, Q3, Gpart, cs, diag, dscale, off, scale;
     DevBuf<int> perm, flag;
+    DevBuf<double> dfac;  // the current panel's factored diagonal block (k_chol_panel -> k_chol_update)
     int bcap = 0;
     int sweeps_total = 0, calls_total = 0;
     int ensure(int b, int nslice) {
@@ -151,9 +152,18 @@ template <typename T> struct DenseWork {
     // Cholesky of the unit-diagonal Gram matrix D G D in place (G <- L); *ok = false when it is not numerically SPD
     int chol_factor(int b, bool* ok) {
         if (flag.n < 1) MMW_TRY(flag.alloc(1));
+        if (dfac.n < (size_t)CH_NB * CH_NB) MMW_TRY(dfac.alloc((size_t)CH_NB * CH_NB));
         hipLaunchKernelGGL(k_scale_sym, dim3(grid_elems(b)), dim3(BLOCK), 0, st, b, G.p, dscale.p);
         hipLaunchKernelGGL(k_apply_scale_sym, dim3(grid_elems((size_t)b * b)), dim3(BLOCK), 0, st, b, G.p, dscale.p);
-        hipLaunchKernelGGL(k_cholesky, dim3(1), dim3(1024), 0, st, b, G.p, flag.p);
+        MMW_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), st));
+        for (int j0 = 0; j0 < b; j0 += CH_NB) {
+            const int below = b - std::min(b, j0 + CH_NB);
+            hipLaunchKernelGGL(k_chol_panel, dim3(std::max(1, (below + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, b, j0, G.p, flag.p, dfac.p);
+            if (below > 0) {
+                const int mt = (below + CH_NB - 1) / CH_NB;
+                hipLaunchKernelGGL(k_chol_update, dim3(mt, mt), dim3(BLOCK), 0, st, b, j0, G.p, (const int*)flag.p, (const double*)dfac.p);
+            }
+        }
         int bad = 0;
         MMW_HIP(hipMemcpyAsync(&bad, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
         MMW_HIP(hipStreamSynchronize(st));
