@@ -116,12 +116,32 @@ __global__ __launch_bounds__(BLOCK) void k_slot_pref(int K, int Z, const double*
 struct GreedyLds {          // one prefetched user
     int k, deg, qdeg, pad;
 };
+// one header per processing position (shared by the attempts of a batch): everything needed to address user order[kk]'s
+// static data without a chain of dependent loads
+struct GreedyHdr {
+    int k, sb, deg, qb;
+    int qdeg, pad;
+    double hk;
+};
+__global__ __launch_bounds__(BLOCK) void k_greedy_headers(int K, const int* __restrict__ order, const int* __restrict__ so_indptr,
+                                                          const int* __restrict__ q_indptr, const double* __restrict__ h_max,
+                                                          GreedyHdr* __restrict__ hdr) {
+    for (int kk = blockIdx.x * BLOCK + threadIdx.x; kk < K; kk += gridDim.x * BLOCK) {
+        const int k = order[kk];
+        GreedyHdr h;
+        h.k = k; h.sb = so_indptr[k]; h.deg = so_indptr[k + 1] - h.sb; h.qb = q_indptr[k]; h.qdeg = q_indptr[k + 1] - h.qb; h.pad = 0;
+        h.hk = h_max[k];
+        hdr[kk] = h;
+    }
+}
+// workgroup barrier that orders LDS traffic only: global loads issued earlier (the prefetch of the next user) stay in flight
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <bool SLOT_LDS>
-__global__ __launch_bounds__(BLOCK) void k_greedy(int K, int Z, int maxdeg, int maxq, const int* __restrict__ order,
-                                                  const int* __restrict__ pref_all, const int* __restrict__ so_indptr,
-                                                  const int* __restrict__ so_indices, const double* __restrict__ so_data,
-                                                  const int* __restrict__ q_indptr, const int* __restrict__ q_indices,
-                                                  const double* __restrict__ h_max, double* __restrict__ gain_all,
+__global__ __launch_bounds__(BLOCK) void k_greedy(int K, int Z, int maxdeg, int maxq, const GreedyHdr* __restrict__ hdr,
+                                                  const int* __restrict__ pref_all, const int* __restrict__ so_indices,
+                                                  const double* __restrict__ so_data, const double* __restrict__ so_hmax,
+                                                  const int* __restrict__ q_indices, double* __restrict__ gain_all,
                                                   int* __restrict__ slot_all, int* __restrict__ rem) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     // layout: [2] x { nid[maxdeg] int, nval[maxdeg] f64, nh[maxdeg] f64, qid[maxq] int, pref[Z] int }, bad[Z] int, slot[K] int (optional)
@@ -144,78 +164,104 @@ __global__ __launch_bounds__(BLOCK) void k_greedy(int K, int Z, int maxdeg, int 
     if (SLOT_LDS)
         for (int i = threadIdx.x; i < K; i += BLOCK) slot_l[i] = -1;
     if (threadIdx.x == 0) unassigned = 0;
-    // everything about user order[kk] that no earlier assignment can change: requested into registers at the top
-    // of the previous user's step (issue), continued after its first barrier (issue2: the loads that need the
-    // neighbour ids), written to the other LDS record at the end of the step (commit) -- never waited for early
+    // Software pipeline over the users, none of its loads depends on another load of the same step:
+    //   step kk   requests the header of user kk+2 (h2) and, with the header of user kk+1 that arrived during step kk-1 (h1),
+    //             that user's neighbour ids, gains, thresholds (so_hmax: h_max of the neighbour, per edge), access-point
+    //             peers and preference row; they are written to the other LDS record at the end of the step (commit).
+    // The barriers inside a step order LDS only (lds_barrier), so these requests stay in flight; the barrier that ends the
+    // step is a full one: it publishes the step's additions to gain[] (global) before the next user's sums are read.
     constexpr int NE = 4;  // neighbour elements per thread: maxdeg <= NE * BLOCK
-    int r_k = 0, r_sb = 0, r_deg = 0, r_qb = 0, r_qdeg = 0;
+    GreedyHdr h1 = hdr[0], h2 = hdr[K > 1 ? 1 : 0];
     int r_n[NE], r_q[NE], r_p[NE];
-    double r_v[NE], r_h[NE], r_hk = 0.0;
-    auto issue = [&](int kk) {
-        r_k = order[kk];
-        r_sb = so_indptr[r_k]; r_deg = so_indptr[r_k + 1] - r_sb;
-        r_qb = q_indptr[r_k]; r_qdeg = q_indptr[r_k + 1] - r_qb;
+    double r_v[NE], r_h[NE];
+    auto issue = [&](const GreedyHdr& h) {
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
             const int e = threadIdx.x + i * BLOCK;
-            r_n[i] = e < r_deg ? so_indices[r_sb + e] : 0;
-            r_v[i] = e < r_deg ? so_data[r_sb + e] : 0.0;
-            r_q[i] = e < r_qdeg ? q_indices[r_qb + e] : 0;
-            r_p[i] = e < Z ? pref[(size_t)r_k * Z + e] : 0;
+            r_n[i] = e < h.deg ? so_indices[h.sb + e] : 0;
+            r_v[i] = e < h.deg ? so_data[h.sb + e] : 0.0;
+            r_h[i] = e < h.deg ? so_hmax[h.sb + e] : 0.0;
+            r_q[i] = e < h.qdeg ? q_indices[h.qb + e] : 0;
+            r_p[i] = e < Z ? pref[(size_t)h.k * Z + e] : 0;
         }
-        r_hk = h_max[r_k];
     };
-    auto issue2 = [&]() {
-#pragma unroll
-        for (int i = 0; i < NE; ++i) r_h[i] = (int)(threadIdx.x + i * BLOCK) < r_deg ? h_max[r_n[i]] : 0.0;
-    };
-    auto commit = [&](int s2) {
+    auto commit = [&](int s2, const GreedyHdr& h) {
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
             const int e = threadIdx.x + i * BLOCK;
-            if (e < r_deg) { nid[s2][e] = r_n[i]; nval[s2][e] = r_v[i]; nh[s2][e] = r_h[i]; }
-            if (e < r_qdeg) qid[s2][e] = r_q[i];
+            if (e < h.deg) { nid[s2][e] = r_n[i]; nval[s2][e] = r_v[i]; nh[s2][e] = r_h[i]; }
+            if (e < h.qdeg) qid[s2][e] = r_q[i];
             if (e < Z) prf[s2][e] = r_p[i];
         }
         if (threadIdx.x == 0) {
-            rec[s2].k = r_k; rec[s2].deg = r_deg; rec[s2].qdeg = r_qdeg;
-            hk[s2] = r_hk;
+            rec[s2].k = h.k; rec[s2].deg = h.deg; rec[s2].qdeg = h.qdeg;
+            hk[s2] = h.hk;
         }
     };
-    issue(0);
-    issue2();
-    commit(0);
+    issue(h1);
+    commit(0, h1);
+    h1 = h2;                                  // header of user 1
+    if (K > 2) h2 = hdr[2];
     __syncthreads();
     for (int kk = 0; kk < K; ++kk) {
         const int cur = kk & 1;
         const bool more = kk + 1 < K;
-        if (more) issue(kk + 1);  // in flight while this user is decided
+        const GreedyHdr hn = h1;               // user kk+1 (arrived during the previous step)
         const int k = rec[cur].k, deg = rec[cur].deg, qdeg = rec[cur].qdeg;
         const double hmk = hk[cur];
-        for (int z = threadIdx.x; z < Z; z += BLOCK) bad[z] = gain[(size_t)k * Z + z] > hmk ? 1 : 0;
+        // the sums on the chain, requested together: the user's own row and, through slot[], each neighbour's sum in its slot
+        double g_self[NE];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int z = threadIdx.x + i * BLOCK;
+            g_self[i] = z < Z ? gain[(size_t)k * Z + z] : 0.0;
+        }
+        int zn_e[NE];
+        double g_ne[NE];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = threadIdx.x + i * BLOCK;
+            zn_e[i] = -1;
+            g_ne[i] = 0.0;
+            if (e < deg) {
+                zn_e[i] = slot[nid[cur][e]];
+                if (zn_e[i] >= 0) g_ne[i] = gain[(size_t)nid[cur][e] * Z + zn_e[i]];
+            }
+        }
+        // the prefetch is requested AFTER the chain loads: loads return in order, so waiting for the chain loads leaves every
+        // younger request in flight
+        if (more) issue(hn);
+        h1 = h2;
+        if (kk + 3 < K) h2 = hdr[kk + 3];      // two steps ahead
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int z = threadIdx.x + i * BLOCK;
+            if (z < Z) bad[z] = g_self[i] > hmk ? 1 : 0;
+        }
         if (threadIdx.x == 0) best = Z;
-        __syncthreads();
-        if (more) issue2();
-        for (int e = threadIdx.x; e < deg; e += BLOCK) {
-            const int n = nid[cur][e];
-            const int zn = slot[n];
-            if (zn >= 0 && gain[(size_t)n * Z + zn] + nval[cur][e] > nh[cur][e]) bad[zn] = 1;
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = threadIdx.x + i * BLOCK;
+            if (e < deg && zn_e[i] >= 0 && g_ne[i] + nval[cur][e] > nh[cur][e]) bad[zn_e[i]] = 1;
         }
         for (int e = threadIdx.x; e < qdeg; e += BLOCK) {
             const int zn = slot[qid[cur][e]];
             if (zn >= 0) bad[zn] = 1;
         }
-        __syncthreads();
+        lds_barrier();
         for (int zz = threadIdx.x; zz < Z; zz += BLOCK)
             if (!bad[prf[cur][zz]]) {
                 atomicMin(&best, zz);
                 break;  // this thread's later candidates are worse
             }
-        __syncthreads();
+        lds_barrier();
         const int zz = best;
         if (zz < Z) {
             const int z = prf[cur][zz];
-            for (int e = threadIdx.x; e < deg; e += BLOCK) gain[(size_t)nid[cur][e] * Z + z] += nval[cur][e];
+            // fire-and-forget f64 atomic adds: one add per address and step, the steps separated by the full barrier below,
+            // so the sums are formed in the reference's order (sdp_solver.py:94) without waiting for a load
+            for (int e = threadIdx.x; e < deg; e += BLOCK) unsafeAtomicAdd(&gain[(size_t)nid[cur][e] * Z + z], nval[cur][e]);
             if (threadIdx.x == 0) {
                 slot[k] = z;
                 if (SLOT_LDS) slot_g[k] = z;
@@ -223,7 +269,7 @@ __global__ __launch_bounds__(BLOCK) void k_greedy(int K, int Z, int maxdeg, int 
         } else if (threadIdx.x == 0) {
             unassigned++;
         }
-        if (more) commit(cur ^ 1);
+        if (more) commit(cur ^ 1, hn);
         __threadfence_block();
         __syncthreads();
     }

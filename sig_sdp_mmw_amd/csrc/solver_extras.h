@@ -14,7 +14,8 @@ template <typename T> struct Extras {
     int K = 0;
     // rounding-side state (float64 whatever T is)
     DevBuf<int> so_indptr, so_indices, q_indptr, q_indices;
-    DevBuf<double> so_data, h_max;
+    DevBuf<double> so_data, h_max, so_hmax;  // so_hmax[e] = h_max[so_indices[e]]: the greedy reads it like so_data
+    DevBuf<GreedyHdr> ghdr;
     DevBuf<double> gX, randv, P, gain, nrm;
     DevBuf<int> pref, slot, order, rem;
     Factorizer<T> fac;
@@ -27,6 +28,12 @@ template <typename T> struct Extras {
         MMW_TRY(so_indptr.upload(H->so_indptr, st));
         MMW_TRY(so_indices.upload(H->so_indices, st));
         MMW_TRY(so_data.upload(H->so_data, st));
+        {
+            std::vector<double> hm(H->so_indices.size());
+            for (size_t e = 0; e < hm.size(); ++e) hm[e] = H->h_max[H->so_indices[e]];
+            MMW_TRY(so_hmax.upload(hm, st));
+        }
+        MMW_TRY(ghdr.alloc((size_t)K));
         MMW_TRY(q_indptr.upload(H->q_indptr, st));
         MMW_TRY(q_indices.upload(H->q_indices, st));
         MMW_TRY(h_max.upload(H->h_max, st));
@@ -179,17 +186,18 @@ template <typename T> struct Extras {
             if (maxdeg > 4 * BLOCK || maxq > 4 * BLOCK || Z > 4 * BLOCK)
                 return fail(MMW_ERR_ARG, "mmw_round: more than 1024 neighbours / slots per user is not supported by the greedy kernel");
             const size_t base = (size_t)2 * ((size_t)maxdeg * 20 + (size_t)maxq * 4 + (size_t)Z * 4) + (size_t)Z * 4;
+            hipLaunchKernelGGL(k_greedy_headers, dim3(grid_elems((size_t)K)), dim3(BLOCK), 0, st, K, order.p, so_indptr.p, q_indptr.p, h_max.p, ghdr.p);
             const bool slot_lds = base + (size_t)K * 4 <= 150 * 1024;
             const size_t sh = base + (slot_lds ? (size_t)K * 4 : 0);
             if (sh > 160 * 1024) return fail(MMW_ERR_ARG, "mmw_round: a user's neighbour list does not fit the greedy kernel's LDS record");
             if (slot_lds) {
                 MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_greedy<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-                hipLaunchKernelGGL((k_greedy<true>), dim3(nb), dim3(BLOCK), sh, st, K, Z, maxdeg, maxq, order.p, pref.p, so_indptr.p, so_indices.p,
-                                   so_data.p, q_indptr.p, q_indices.p, h_max.p, gain.p, slot.p, rem.p);
+                hipLaunchKernelGGL((k_greedy<true>), dim3(nb), dim3(BLOCK), sh, st, K, Z, maxdeg, maxq, (const GreedyHdr*)ghdr.p, pref.p, so_indices.p,
+                                   so_data.p, so_hmax.p, q_indices.p, gain.p, slot.p, rem.p);
             } else {
                 MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_greedy<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-                hipLaunchKernelGGL((k_greedy<false>), dim3(nb), dim3(BLOCK), sh, st, K, Z, maxdeg, maxq, order.p, pref.p, so_indptr.p, so_indices.p,
-                                   so_data.p, q_indptr.p, q_indices.p, h_max.p, gain.p, slot.p, rem.p);
+                hipLaunchKernelGGL((k_greedy<false>), dim3(nb), dim3(BLOCK), sh, st, K, Z, maxdeg, maxq, (const GreedyHdr*)ghdr.p, pref.p, so_indices.p,
+                                   so_data.p, so_hmax.p, q_indices.p, gain.p, slot.p, rem.p);
             }
         }
         if (kt) MMW_TRY(kt->end());
