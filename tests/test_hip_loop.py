@@ -207,3 +207,24 @@ def test_blocking_on_mid_size_graphs(kind):
         s.iterate(nit, sk)
         assert relerr(s.read(_lib.F_XHALF), o.trace["X_half"][-1]) < bar, (kind, dtype, info)
         s.close()
+
+
+@pytest.mark.parametrize("Z", [2, 3, 17])
+def test_blocked_kernels_with_narrow_and_ragged_blocks(Z):
+    """D = 2Z = 4, 6, 34 columns: narrower than one 128-byte half tile / not a multiple of it.  The half-tile SpMM and SDDMM
+    must mask the columns past the block's width (gathers, deposits, stores) and still match the oracle."""
+    from sig_sdp_mmw_amd.graphs import journal_graph
+    state = journal_graph(12, 0.012, seed=5)
+    K = state[0].shape[0]
+    nit = 3
+    rng = np.random.default_rng(2)
+    sk = np.stack([orc.sketch_rows(rng.standard_normal((K, 2 * Z))) for _ in range(nit)])
+    o = orc.MMWOracle(nit=nit, eta=0.05)
+    o.run(Z, state, lambda i, K_, D_: sk[i], keep_trace=True, factor=False)
+    for dtype, bar in ((_lib.F64, 1e-9), (_lib.F32, 1e-5)):
+        s = _lib.Solver(Z, state, nit, 0.05, dtype=dtype)
+        s.set_expm(_lib.EXPM_LANCZOS, 16, 1e-12 if dtype == _lib.F64 else 1e-7)
+        assert s.read(_lib.F_BLOCKING)[0] == 1.0
+        s.iterate(nit, sk)
+        assert relerr(s.read(_lib.F_XHALF), o.trace["X_half"][-1]) < bar, (Z, dtype)
+        s.close()
