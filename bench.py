@@ -1,25 +1,37 @@
 #!/usr/bin/env python3
 """Benchmark of the MMW hot path on MI355X: MMW iterations/s on the configuration BASELINE.json's
-metric is quoted on (N = 10 k, 1 %-sparse interference graph from the journal generator, fp32).
+metric is quoted on (N = 10 k, 1 %-sparse interference graph from the journal generator, fp32), and the
+wall-clock of the whole binary search to a converged colouring on the same instance.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--expm lanczos|taylor]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--instances-per-gpu M] [--expm lanczos|taylor]
 
 One "step" = one MMW iteration (DUAL, LOSS, EXPM + X on the pattern, averaging) on a synthetic instance
 that is resident in HBM before the timed region starts; the sketches are generated on the device.
-N > 1: one process per GPU (torchrun), each rank solves its own independent instance (weak scaling,
-instance sharding -- the path has no data-path collective); the per-instance objectives are gathered
-with one RCCL all_gather at the end of the timed region.
+
+N > 1: one process per GPU.  Either an external launcher started the ranks (torchrun: RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in the environment), or -- with WORLD_SIZE unset -- this process starts them itself:
+it spawns N fresh children *before touching the GPU* (no torch.cuda, no HIP call in the parent), relays
+rank 0's JSON line and exits non-zero if any rank fails.  Every rank solves its own independent instances
+(weak scaling, instance sharding -- the path has no data-path collective); the per-instance objectives are
+gathered with one RCCL all_gather that closes the timed region.
+
+--instances-per-gpu M (BASELINE configs[3]: 64 N=2000 graphs, 8 per GPU: `--workload er-5pct-2k
+--instances-per-gpu 8`): M resident handles per rank, their iterations enqueued round-robin on M HIP streams.
 
 The JSON line also carries
   roofline     : the CSR SpMM inside exp(L/2)R -- algorithmic bytes per launch
                  divided by its mean launch duration, measured with HIP events on the solver's stream
                  in a second pass over the same steps;
+  coloring     : wall-clock of the binary search on the slot count down to a feasible colouring of the same instance
+                 (rank 0, N = 1, one instance per GPU), with the per-probe phase times;
   cpu_baseline : the CPU oracle (oracle/mmw_oracle.py, a NumPy/SciPy port of the reference loop)
                  timed on this host on a bounded number of iterations of the same instance (rank 0, N=1).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -51,11 +63,98 @@ def make_state(kind, kw):
 
 def first_midpoint(state):
     """The slot count the reference's binary search probes first (binary_search_relaxation.py:13-29,46)."""
-    S, Q, _ = state
-    T = (S + S.T).tocsr()
-    ub = int(np.max(np.diff(T.indptr))) + 1  # the diagonal stays stored after setdiag(0), as executed
-    lb = int(np.max(np.diff(Q.indptr))) + 1
+    from sig_sdp_mmw_amd.binary_search import binary_search_relaxation
+    lb, ub = binary_search_relaxation().set_bounds(state)
     return (lb + ub) // 2
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n, cmd, env=None, timeout=None):
+    """Start `n` fresh processes running `cmd` (a list), one per rank, with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set; nothing in this (parent) process touches the GPU.  Rank 0's stdout is
+    captured and returned, the other ranks' stdout goes to stderr.  Returns (exit code, rank-0 stdout):
+    the exit code is the first non-zero child status (the remaining children are then terminated by PID)."""
+    base = dict(os.environ if env is None else env)
+    base.setdefault("MASTER_ADDR", "127.0.0.1")
+    base["MASTER_PORT"] = str(free_port())
+    base["WORLD_SIZE"] = str(n)
+    base["LOCAL_WORLD_SIZE"] = str(n)
+    procs = []
+    for r in range(n):
+        e = dict(base)
+        e["RANK"] = str(r)
+        e["LOCAL_RANK"] = str(r)
+        procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    t0 = time.time()
+    rc = 0
+    out0 = ""
+    live = set(range(n))
+    try:
+        while live:
+            for r in sorted(live):
+                p = procs[r]
+                if r == 0:
+                    try:
+                        o, _ = p.communicate(timeout=0.2)
+                        out0 += o or ""
+                    except subprocess.TimeoutExpired:
+                        continue
+                elif p.poll() is None:
+                    continue
+                live.discard(r)
+                if p.returncode != 0 and rc == 0:
+                    rc = p.returncode
+            if rc != 0 or (timeout is not None and time.time() - t0 > timeout):
+                if rc == 0:
+                    rc = 124
+                break
+            if live and 0 not in live:
+                time.sleep(0.1)
+    finally:
+        for r in live:  # a rank failed or timed out: stop exactly the children started here
+            p = procs[r]
+            if p.poll() is None:
+                p.terminate()
+        for r in live:
+            try:
+                o, _ = procs[r].communicate(timeout=20)
+                if r == 0:
+                    out0 += o or ""
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+    return rc, out0
+
+
+def coloring_block(state, dtype_name, nit, eta, warm):
+    """Wall-clock of the whole binary search (binary_search_relaxation.run) to a feasible colouring, with the device-RNG /
+    batched-rounding fast path of the drop-in class (the flow of sim_script/journal_version/sim_mmw_time.py:30-36)."""
+    from sig_sdp_mmw_amd.binary_search import binary_search_relaxation
+    from sig_sdp_mmw_amd.mmw import mmw
+    bs = binary_search_relaxation()
+    bs.verbose = False
+    alg = mmw(nit=nit, eta=eta, dtype=dtype_name, rng="device", seed=1, warm_start=warm)
+    bs.feasibility_check_alg = alg
+    np.random.seed(0)
+    t0 = time.perf_counter()
+    z_vec, Z, rem = bs.run(state)
+    wall = time.perf_counter() - t0
+    per = bs.LOGGED_NP_DATA["bs_search_per_it"]
+    lg = alg.LOGGED_NP_DATA
+    alg.close()
+    ms = lambda us: round(float(us) / 1e3, 2)
+    return {"wall_s": round(wall, 4), "Z": int(Z), "rem": int(rem), "probes": int(per.shape[0]), "nit_per_probe": int(nit),
+            "warm_start": bool(warm), "mids": [int(x) for x in per[:, 5]], "rems": [int(x) for x in per[:, 7]],
+            "iterations": [int(x) for x in lg["mmw_iters"][:, 5]] if "mmw_iters" in lg else None,
+            "per_probe_ms": {"solve": [ms(x) for x in per[:, 8]], "rounding": [ms(x) for x in per[:, 9]],
+                             "state_process": [ms(x) for x in lg["mmw_state_process"][:, 5]],
+                             "factor": [ms(x) for x in lg["mmw_xavg"][:, 5]]}}
 
 
 def main():
@@ -64,23 +163,31 @@ def main():
     ap.add_argument("--steps", type=int, default=150)   # nit = 150 is the reference's production setting
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="journal-1pct", choices=sorted(WORKLOADS))
+    ap.add_argument("--instances-per-gpu", type=int, default=1, help="resident handles per rank, iterations enqueued round-robin (configs[3]: 8)")
     ap.add_argument("--expm", default="lanczos", choices=["lanczos", "taylor"])
     ap.add_argument("--dtype", default=None, choices=["f32", "f64"])
     ap.add_argument("--eta", type=float, default=0.04)
     ap.add_argument("--cpu-iters", type=int, default=-1, help="oracle iterations for cpu_baseline (-1: auto, 0: skip)")
+    ap.add_argument("--no-coloring", action="store_true", help="skip the binary search to a converged colouring")
+    ap.add_argument("--coloring-nit", type=int, default=150)
+    ap.add_argument("--coloring-cold", action="store_true", help="every probe restarts from Y = 1/C, X = I like the reference (mmw.py:62-68)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --single-device rehearses N>1 on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="every rank uses GPU 0 (rehearsal only)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: be the launcher.  Nothing above this line has touched the GPU.
+        rc, out0 = spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+        raise SystemExit(rc)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs one process per GPU: python -m torch.distributed.run --nnodes=1 "
-                             "--nproc-per-node %d --master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." %
-                             (args.gpus, args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    M = max(1, args.instances_per_gpu)
 
     import torch
     dist = None
@@ -99,19 +206,25 @@ def main():
     coll_dev = "cuda" if args.backend == "nccl" else "cpu"
 
     from sig_sdp_mmw_amd import _lib
+    from sig_sdp_mmw_amd import sharding
 
     desc, factory, Zfix, dt_default = WORKLOADS[args.workload]
     dtype_name = args.dtype or dt_default
     dtype = _lib.F32 if dtype_name == "f32" else _lib.F64
     w = 4 if dtype_name == "f32" else 8
-    kind, kw = factory(rank)  # every rank gets its own instance (seed = rank)
-    state = make_state(kind, kw)
-    Z = Zfix if Zfix is not None else first_midpoint(state)
+    n_inst = world * M
+    mine = sharding.instances_of_rank(n_inst, rank, world)  # instance i -> rank i % world; its seed is its id
+    states = [make_state(*factory(i)) for i in mine]
+    Zs = [Zfix if Zfix is not None else first_midpoint(st) for st in states]
     nit = args.warmup + args.steps
-    solver = _lib.Solver(Z, state, nit, args.eta, dtype=dtype, device=local_rank)
     method = _lib.EXPM_LANCZOS if args.expm == "lanczos" else _lib.EXPM_TAYLOR
-    solver.set_expm(method, 12, 1e-6 if dtype_name == "f32" else 1e-9)
-    seed = 1234 + rank
+    solvers = []
+    for st, Z in zip(states, Zs):
+        s = _lib.Solver(Z, st, nit, args.eta, dtype=dtype, device=local_rank)
+        s.set_expm(method, 12, 1e-6 if dtype_name == "f32" else 1e-9)
+        solvers.append(s)
+    solver, state, Z = solvers[0], states[0], Zs[0]
+    seeds = [1234 + i for i in mine]
 
     def barrier():
         torch.cuda.synchronize()
@@ -119,18 +232,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warmup, then the timed region: exactly `steps` iterations
-    solver.iterate(args.warmup, None, seed)
-    solver.sync()
+    def run_steps(n):
+        """n iterations of every resident instance; with several instances the calls are interleaved in chunks so that
+        their streams overlap on the device (every mmw_iterate returns once its work is enqueued)."""
+        if len(solvers) == 1:
+            solvers[0].iterate(n, None, seeds[0])
+        else:
+            chunk = 16
+            for s0 in range(0, n, chunk):
+                for s, sd in zip(solvers, seeds):
+                    s.iterate(min(chunk, n - s0), None, sd)
+        for s in solvers:
+            s.sync()
+
+    # ---- warmup, then the timed region: exactly `steps` iterations (of every instance)
+    run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    solver.iterate(args.steps, None, seed)
-    solver.sync()
-    from sig_sdp_mmw_amd import sharding
+    run_steps(args.steps)
     # per-instance objective record, gathered to every rank (RCCL all_gather over xGMI, 48 B per instance)
-    rec = [rank, Z, 0.0, float(np.max(solver.read(_lib.F_E_THIS))), args.steps, (time.perf_counter() - t0) * 1e6]
-    table = sharding.gather_records([rec], world, rank, world, dist=dist, device=coll_dev if dist is not None else None)
-    assert table.shape[0] == world
+    wall_us = (time.perf_counter() - t0) * 1e6
+    recs = [[i, Zi, 0.0, float(np.max(s.read(_lib.F_E_THIS))), args.steps, wall_us] for i, Zi, s in zip(mine, Zs, solvers)]
+    table = sharding.gather_records(recs, n_inst, rank, world, dist=dist, device=coll_dev if dist is not None else None)
+    assert table.shape[0] == n_inst, table.shape
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
@@ -141,11 +265,11 @@ def main():
     info = solver.read(_lib.F_EXPM_INFO)
     m_used = int(info[1])
 
-    # ---- roofline pass: the same number of steps again with HIP events around every kernel class
+    # ---- roofline pass: the same number of steps again with HIP events around every kernel class (first instance)
     solver.reset(nit)
-    solver.iterate(args.warmup, None, seed)
+    solver.iterate(args.warmup, None, seeds[0])
     solver.set_profile(True)
-    solver.iterate(args.steps, None, seed)
+    solver.iterate(args.steps, None, seeds[0])
     kt = solver.kernel_times()
     solver.set_profile(False)
     spmm_us, spmm_n = kt["spmm"]
@@ -160,27 +284,37 @@ def main():
                 rec = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 if rec.get("workload") == args.workload and dtype_name == "f32" and args.expm == "lanczos":
                     traffic = rec["traffic_bytes_per_launch"]
+                    traffic_src = "profiles/" + fn
             except Exception:
                 pass
-    blocked = bool(solver.read(_lib.F_BLOCKING)[0])
-    kname = ("k_spmm_blk2 (LDS-staged locality-blocked CSR SpMM, 128-byte half tiles" if blocked else "k_spmm (generic CSR gather SpMM") + " of the %s step)" % args.expm
-    roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1),
+    kinfo = solver.spmm_kernel_info()
+    roofline = {"bound": "hbm", "kernel": kinfo["name"] + " of the %s step" % args.expm, "limiter": kinfo["limiter"],
+                "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": traffic_src if traffic is not None else None,
                 "bytes_per_launch": int(b_spmm), "avg_launch_us": round(spmm_avg_us, 2), "launches": int(spmm_n),
                 "launches_per_step": round(spmm_n / max(args.steps, 1), 2)}
     phases = {k: round(v[0] / max(args.steps, 1), 2) for k, v in kt.items() if v[1]}
 
     out = {
-        "metric": "mmw_iterations_per_sec", "value": round(world * args.steps / elapsed, 2), "unit": "it/s",
+        "metric": "mmw_iterations_per_sec", "value": round(n_inst * args.steps / elapsed, 2), "unit": "it/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
         "config": {"workload": args.workload, "description": desc, "K": K, "Z": Z, "D": D, "nnzL": nnzL, "C": C,
                    "eta": args.eta, "expm": args.expm, "krylov_order": m_used, "rng": "device-philox4x32",
-                   "instances": world, "parallelism": "instance-sharded x%d" % world},
+                   "instances": n_inst, "instances_per_gpu": M,
+                   "parallelism": "instance-sharded x%d" % world + (", %d resident per GPU" % M if M > 1 else "")},
+        "instances_per_s": round(n_inst / elapsed, 3),  # solves of `steps` iterations per second, whole job
         "roofline": roofline,
         "device_us_per_step": phases,
         "objectives": {"max_violation_per_instance": [round(float(x), 6) for x in table[:, 3]]},
     }
+
+    # ---- wall-clock to a converged colouring: the whole binary search on the same instance (rank 0, N = 1 only)
+    if rank == 0 and world == 1 and M == 1 and not args.no_coloring:
+        for s in solvers[1:]:
+            s.close()
+        out["coloring"] = coloring_block(state, dtype_name, args.coloring_nit, args.eta, warm=not args.coloring_cold)
 
     # ---- CPU baseline: the oracle on this host, bounded sample of the same instance (rank 0, N = 1 only)
     if rank == 0 and world == 1 and args.cpu_iters != 0:
@@ -202,7 +336,8 @@ def main():
                                "host_cpus": os.cpu_count()}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    solver.close()
+    for s in solvers:
+        s.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -120,6 +120,15 @@ int mmw_reset(mmw_solver* s, int32_t nit);
  * rebuilt, the pattern, its locality blocking and the device copies of the state are reused; then mmw_reset(nit).
  */
 int mmw_set_slots(mmw_solver* s, int32_t Z, int32_t nit);
+/*
+ * mmw_set_slots_warm: the same rebinding, but the next run CONTINUES from the previous probe's iterate instead of the
+ * reference's initial point (opt-in warm start of the binary search, binary_search_relaxation.py:44-72 calls the solver
+ * once per probed Z and the reference restarts each time, mmw.py:62-68): e_accu, L_accu and the last X / Y are kept, the
+ * running sums of X and Y restart from them.  Falls back to mmw_set_slots when the handle has not iterated yet.
+ */
+int mmw_set_slots_warm(mmw_solver* s, int32_t Z, int32_t nit);
+/* step size for the iterations that follow (the reference reads self.eta on every run, mmw.py:137,167) */
+int mmw_set_eta(mmw_solver* s, double eta);
 
 /*
  * mmw_iterate: `n` passes of the loop body mmw.py:75-200 (averaging, DUAL, LOSS, EXPM), device resident.

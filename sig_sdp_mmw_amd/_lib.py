@@ -21,7 +21,7 @@ KERNEL_CLASSES = ["spmm", "sddmm", "dual", "loss", "krylov_vec", "sketch", "proj
 I_L_INDPTR, I_L_INDICES, I_ST_INDPTR, I_ST_INDICES, I_GAIN_X, I_GAIN_Y, I_ASSO_X, I_ASSO_Y, I_DIAG_POS, I_ASSO_POS = range(10)
 
 EXPORTS = ["mmw_last_error", "mmw_version", "mmw_device_count", "mmw_create", "mmw_destroy", "mmw_sizes", "mmw_set_expm",
-           "mmw_set_timing", "mmw_set_profile", "mmw_bench_spmm", "mmw_reset", "mmw_set_slots", "mmw_iterate", "mmw_sync", "mmw_read_f64", "mmw_read_i32", "mmw_gap",
+           "mmw_set_timing", "mmw_set_profile", "mmw_bench_spmm", "mmw_reset", "mmw_set_slots", "mmw_set_slots_warm", "mmw_set_eta", "mmw_iterate", "mmw_sync", "mmw_read_f64", "mmw_read_i32", "mmw_gap",
            "mmw_factor", "mmw_expm_apply", "mmw_round"]
 
 
@@ -57,6 +57,8 @@ def lib():
     L.mmw_bench_spmm.argtypes = [C.c_void_p, C.c_int, C.c_int, p_f64]
     L.mmw_reset.argtypes = [C.c_void_p, C.c_int32]
     L.mmw_set_slots.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    L.mmw_set_slots_warm.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    L.mmw_set_eta.argtypes = [C.c_void_p, C.c_double]
     L.mmw_iterate.argtypes = [C.c_void_p, C.c_int32, p_f64, C.c_uint64]
     L.mmw_sync.argtypes = [C.c_void_p]
     L.mmw_read_f64.argtypes = [C.c_void_p, C.c_int, p_f64, C.c_int64]
@@ -173,9 +175,21 @@ class Solver:
         check(lib().mmw_reset(self._h, int(nit)))
         self._timed = 0
 
-    def set_slots(self, Z, nit):
-        """Rebind to another slot count on the same state (keeps pattern, blocking and device copies)."""
-        check(lib().mmw_set_slots(self._h, int(Z), int(nit)))
+    def set_eta(self, eta):
+        check(lib().mmw_set_eta(self._h, float(eta)))
+
+    def spmm_kernel_info(self):
+        """Which SpMM kernel exp(L/2)R runs on for this handle, and what bounds it (for the benchmark's roofline record)."""
+        blocked = bool(self.read(F_BLOCKING)[0])
+        if blocked:
+            return {"name": "k_spmm_blk2 (LDS-staged locality-blocked CSR SpMM, 128-byte half tiles)",
+                    "limiter": "VALU issue + LDS latency; operands live in L2 / Infinity Cache, not HBM"}
+        return {"name": "k_spmm (generic CSR gather SpMM)", "limiter": "L2 gather rate of the dense rows"}
+
+    def set_slots(self, Z, nit, warm=False):
+        """Rebind to another slot count on the same state (keeps pattern, blocking and device copies).
+        warm=True continues from the previous probe's iterate (mmw_set_slots_warm)."""
+        check((lib().mmw_set_slots_warm if warm else lib().mmw_set_slots)(self._h, int(Z), int(nit)))
         sz = (C.c_int64 * 10)()
         check(lib().mmw_sizes(self._h, sz))
         (self.K, self.Z, self.D, self.Dpad, self.nnzL, self.nnzST, self.E_gain, self.E_asso, self.C, _) = [int(x) for x in sz]

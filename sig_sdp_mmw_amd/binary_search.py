@@ -27,8 +27,13 @@ class binary_search_relaxation(STATS_OBJECT):
             return lb, lb
         if self.force_full_bound:
             return 1, S.shape[0]
-        sym = (S + S.transpose()).tocsr()  # the diagonal stays stored, as in the reference (:23)
-        ub = int(np.max(np.diff(sym.indptr))) + 1
+        # The reference zeroes the diagonal of S + S^T with setdiag(0) (:23), which leaves one STORED entry per row whether or
+        # not the row had a diagonal before: its count is (off-diagonal entries of the row) + 1, and the bound adds one more.
+        sym = (S + S.transpose()).tocsr()
+        sym.sum_duplicates()
+        rows = np.repeat(np.arange(sym.shape[0]), np.diff(sym.indptr))
+        offdiag = np.bincount(rows[sym.indices != rows], minlength=sym.shape[0])
+        ub = int(np.max(offdiag)) + 2
         lb = int(np.max(np.diff(Q.indptr))) + 1
         return lb, ub
 

@@ -22,7 +22,8 @@ struct mmw_solver {
     virtual int set_profile(int enabled) = 0;
     virtual int bench_spmm(int blocked, int reps, double* avg_us) = 0;
     virtual int reset(int32_t nit) = 0;
-    virtual int set_slots(int32_t Z, int32_t nit) = 0;
+    virtual int set_slots(int32_t Z, int32_t nit, int warm) = 0;
+    virtual int set_eta(double eta) = 0;
     virtual int iterate(int32_t n, const double* randv, uint64_t seed) = 0;
     virtual int sync() = 0;
     virtual int read_f64(int which, double* out, int64_t n) = 0;
@@ -390,11 +391,21 @@ template <typename T> struct Solver final : mmw_solver {
     }
 
     // same state, new slot count: only the Z-dependent scalars and the D-wide blocks change
-    int set_slots(int32_t Z_, int32_t nit_) override {
+    int set_eta(double eta_) override {
+        if (!(eta_ >= 0.0)) return fail(MMW_ERR_ARG, "eta must be non-negative");
+        if (!host_only) {
+            MMW_HIP(hipSetDevice(device));
+            MMW_TRY(settle());  // a pending chunk was enqueued with the old step size; a replay must use it too
+        }
+        eta = eta_;
+        return MMW_OK;
+    }
+    int set_slots(int32_t Z_, int32_t nit_, int warm) override {
         if (host_only) return fail(MMW_ERR_STATE, "this handle was created with device -1 (host pattern only)");
         MMW_HIP(hipSetDevice(device));
         MMW_TRY(settle());
         MMW_HIP(hipStreamSynchronize(st));
+        if (warm && iter == 0) warm = 0;  // nothing to continue from
         std::string err = update_slots(H, Z_);
         if (!err.empty()) return fail(MMW_ERR_ARG, "mmw_set_slots: " + err);
         Z = Z_;
@@ -408,7 +419,22 @@ template <typename T> struct Solver final : mmw_solver {
         const size_t nnz = (size_t)H.nnzL(), C = (size_t)H.C();
         MMW_TRY(out64.alloc(std::max(std::max(nnz, C), eng.bs)));
         MMW_TRY(stage64.alloc((size_t)K * D));
-        return reset(nit_);
+        return warm ? restart_warm(nit_) : reset(nit_);
+    }
+    // Warm start of the next probe of the binary search (opt-in; the reference restarts every probe from Y = 1/C, X = I,
+    // mmw.py:62-68): the accumulated violations e_accu, the accumulated loss L_accu and the last X / Y are kept, the
+    // running sums restart from that X / Y, the iteration counter from zero.
+    int restart_warm(int32_t nit_) {
+        if (nit_ < 1) return fail(MMW_ERR_ARG, "nit must be >= 1");
+        nit = nit_;
+        iter = 0;
+        pending = false;
+        if (eng.viol_d.p) MMW_TRY(eng.clear_violation());
+        const size_t nnz = (size_t)H.nnzL(), C = (size_t)H.C();
+        MMW_HIP(hipMemcpyAsync(xavg.p, xval.p, nnz * sizeof(T), hipMemcpyDeviceToDevice, st));
+        MMW_HIP(hipMemcpyAsync(yavg.p, Y.p, C * sizeof(T), hipMemcpyDeviceToDevice, st));
+        phase_us.clear();
+        return MMW_OK;
     }
     int reset(int32_t nit_) override {
         if (host_only) return fail(MMW_ERR_STATE, "this handle was created with device -1 (host pattern only)");
@@ -777,6 +803,7 @@ template <typename T> struct Solver final : mmw_solver {
     }
     int round(int32_t Zr, int32_t Dp, const double* gX, int32_t nbatch, const double* randv, int32_t* z_out, int32_t* rem_out) override {
         if (host_only) return fail(MMW_ERR_STATE, "host-only handle");
+        MMW_HIP(hipSetDevice(device));
         return extras.round(Zr, Dp, gX, nbatch, randv, z_out, rem_out);
     }
 };
@@ -842,7 +869,7 @@ int expm_apply_impl(int device, int method, int max_order, double tol, int32_t K
 extern "C" {
 
 const char* mmw_last_error(void) { return last_error_ref().c_str(); }
-int mmw_version(void) { return 100; }
+int mmw_version(void) { return 200; }
 int mmw_device_count(int* n) {
     if (!n) return fail(MMW_ERR_ARG, "null pointer");
     int c = 0;
@@ -897,7 +924,9 @@ int mmw_set_timing(mmw_solver* s, int enabled) { MMW_NEED(s); return s->set_timi
 int mmw_set_profile(mmw_solver* s, int enabled) { MMW_NEED(s); return s->set_profile(enabled); }
 int mmw_bench_spmm(mmw_solver* s, int blocked, int reps, double* avg_us) { MMW_NEED(s); return s->bench_spmm(blocked, reps, avg_us); }
 int mmw_reset(mmw_solver* s, int32_t nit) { MMW_NEED(s); return s->reset(nit); }
-int mmw_set_slots(mmw_solver* s, int32_t Z, int32_t nit) { MMW_NEED(s); return s->set_slots(Z, nit); }
+int mmw_set_slots(mmw_solver* s, int32_t Z, int32_t nit) { MMW_NEED(s); return s->set_slots(Z, nit, 0); }
+int mmw_set_slots_warm(mmw_solver* s, int32_t Z, int32_t nit) { MMW_NEED(s); return s->set_slots(Z, nit, 1); }
+int mmw_set_eta(mmw_solver* s, double eta) { MMW_NEED(s); return s->set_eta(eta); }
 int mmw_iterate(mmw_solver* s, int32_t n, const double* randv, uint64_t seed) { MMW_NEED(s); return s->iterate(n, randv, seed); }
 int mmw_sync(mmw_solver* s) { MMW_NEED(s); return s->sync(); }
 int mmw_read_f64(mmw_solver* s, int which, double* out, int64_t n) { MMW_NEED(s); if (!out && n) return fail(MMW_ERR_ARG, "null output"); return s->read_f64(which, out, n); }

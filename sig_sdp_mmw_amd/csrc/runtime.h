@@ -58,7 +58,10 @@ template <typename T> struct DevBuf {
     }
     int upload(const std::vector<T>& h, hipStream_t st) {
         MMW_TRY(alloc(h.size()));
-        if (!h.empty()) MMW_HIP(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
+        if (!h.empty()) {
+            MMW_HIP(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
+            MMW_HIP(hipStreamSynchronize(st));  // the source may be a short-lived host vector
+        }
         return MMW_OK;
     }
     // upload a double host vector converted to T

@@ -11,14 +11,19 @@ Same class surface as the reference's `mmw` (sim_src/alg/mmw.py:12-229):
 Every per-iteration quantity lives on the GPU for the whole call; the host calls through the ctypes
 C-ABI of include/mmw_hip.h.  There is no CPU path: a missing library or GPU raises `MMWError`.
 
-Extra keyword-only options (the reference has none of them):
-  dtype   "f64" (default, the reference's arithmetic) or "f32"
+Extra keyword-only options (the reference has none of them).  `dtype`, `rng` and `expm_tol` left at None take their
+defaults from the environment, so that a harness script that constructs `mmw(nit=150, eta=0.04)` unchanged
+(sim_script/journal_version/sim_mmw_time.py:34, sim_script/pd_mmw_template.py:26) can be put on the fast path from outside:
+  dtype   "f64" (default, the reference's arithmetic) or "f32"                       [$MMW_DTYPE]
   rng     "host": the K x D sketch of every iteration is drawn from the global NumPy stream exactly
           like mmw.py:226-227 and uploaded (a seeded run then consumes `np.random` like the
           reference does, including the one `standard_normal(K)` its `svds` start vector takes);
-          "device": Philox sketches generated on the GPU (the fast path).
-  expm    "lanczos" (default) or "taylor"; expm_tol, expm_max_order tune the Krylov order choice.
+          "device": Philox sketches generated on the GPU (the fast path).              [$MMW_RNG]
+  expm    "lanczos" (default) or "taylor"; expm_tol [$MMW_EXPM_TOL], expm_max_order tune the Krylov order choice.
   device  HIP device index (default: $LOCAL_RANK or 0).
+  warm_start  False (default, the reference's behaviour: every run restarts from Y = 1/C, X = I, mmw.py:62-68) or True:
+          a run on the state of the previous run continues from that run's (e_accu, L_accu, X, Y) and averages
+          `warm_fraction * nit` iterations only -- the probes of one binary search solve neighbouring problems.  [$MMW_WARM_START]
 """
 import math
 import os
@@ -33,11 +38,17 @@ _SKETCH_CHUNK_BYTES = 64 << 20
 
 
 class mmw(STATS_OBJECT, sdp_solver):
-    def __init__(self, nit=100, rank_radio=2, alpha=1., eta=0.1, log_gap=False, *, dtype="f64", rng="host",
-                 expm="lanczos", expm_tol=None, expm_max_order=12, device=None, seed=0):
+    def __init__(self, nit=100, rank_radio=2, alpha=1., eta=0.1, log_gap=False, *, dtype=None, rng=None,
+                 expm="lanczos", expm_tol=None, expm_max_order=12, device=None, seed=0, warm_start=None, warm_fraction=1.0 / 3.0):
         sdp_solver.__init__(self, nit=nit, rank_radio=rank_radio, alpha=alpha)
         self.eta = eta
         self.LOG_GAP = log_gap
+        dtype = os.environ.get("MMW_DTYPE", "f64") if dtype is None else dtype
+        rng = os.environ.get("MMW_RNG", "host") if rng is None else rng
+        if expm_tol is None and os.environ.get("MMW_EXPM_TOL"):
+            expm_tol = float(os.environ["MMW_EXPM_TOL"])
+        if warm_start is None:
+            warm_start = os.environ.get("MMW_WARM_START", "0") not in ("", "0")
         if dtype not in ("f32", "f64") or rng not in ("host", "device") or expm not in ("lanczos", "taylor"):
             raise ValueError("dtype in {f32,f64}, rng in {host,device}, expm in {lanczos,taylor}")
         self.dtype, self.rng, self.expm = dtype, rng, expm
@@ -49,6 +60,8 @@ class mmw(STATS_OBJECT, sdp_solver):
         self._runs = 0
         self.last_expm_info = None
         self.round_batch = rng == "device"  # the fast path batches the rounding attempts too
+        self.warm_start = bool(warm_start)
+        self.warm_fraction = float(warm_fraction)
 
     def run_with_state(self, bs_iteration, Z, state):
         tic = self._get_tic()
@@ -62,7 +75,11 @@ class mmw(STATS_OBJECT, sdp_solver):
         sp_tic = self._get_tic()
         K = state[0].shape[0]
         nit = int(self.nit)
-        solver = self._device_solver(Z, state, nit=nit, eta=self.eta, need_loop=True)
+        warm = self.warm_start and self._same_state(state) and self._dev[2].iterations_done > 0
+        if warm:  # continue from the previous probe's iterate and average fewer iterations
+            nit = max(1, int(math.ceil(nit * self.warm_fraction)))
+        solver = self._device_solver(Z, state, nit=nit, eta=self.eta, need_loop=True, warm=warm)
+        self._add_np_log("mmw_iters", 0, np.array([Z, K, nit, 1.0 if warm else 0.0]))
         solver.set_expm(_lib.EXPM_LANCZOS if self.expm == "lanczos" else _lib.EXPM_TAYLOR, self.expm_max_order, self.expm_tol)
         solver.set_timing(True)
         D = solver.D

@@ -30,31 +30,40 @@ class sdp_solver:
                 float(np.asarray(h)[:8].sum()))
 
     def _same_state(self, state):
+        """Content comparison with the arrays the handle was created from (copies taken then): in-place edits of
+        `S.data` between two calls are seen, like the reference which re-reads the state on every run (mmw.py:28)."""
         if self._dev is None:
             return False
         key, held, _ = self._dev
         if key != self._state_key(state):
             return False
         S, Q, h = state
-        S0, Q0, h0 = held
-        return (S is S0 or (np.array_equal(S.indptr, S0.indptr) and np.array_equal(S.indices, S0.indices) and
-                            np.array_equal(S.data, S0.data))) and \
-               (Q is Q0 or (np.array_equal(Q.indptr, Q0.indptr) and np.array_equal(Q.indices, Q0.indices))) and \
-               np.array_equal(np.asarray(h), np.asarray(h0))
+        (sp0, si0, sx0), (qp0, qi0), h0 = held
+        return np.array_equal(S.indptr, sp0) and np.array_equal(S.indices, si0) and np.array_equal(S.data, sx0) and \
+            np.array_equal(Q.indptr, qp0) and np.array_equal(Q.indices, qi0) and np.array_equal(np.asarray(h), h0)
 
-    def _device_solver(self, Z, state, nit=1, eta=0.1, need_loop=False):
+    def _device_solver(self, Z, state, nit=1, eta=None, need_loop=False, warm=False):
         """A device handle holding `state` (reused across the binary search's solve/rounding pairs)."""
         if self._same_state(state):
             s = self._dev[2]
             if need_loop:  # same state, another slot count: keep pattern, blocking and device copies
-                s.set_slots(max(int(Z), 2), max(int(nit), 1))
+                if eta is not None:
+                    s.set_eta(eta)  # the reference reads self.eta on every run
+                s.set_slots(max(int(Z), 2), max(int(nit), 1), warm=warm)
             return s
+        self.close()
+        s = _lib.Solver(max(int(Z), 2), state, max(int(nit), 1), 0.1 if eta is None else eta, rank_radio=self.rank_radio,
+                        dtype=self._dtype_code, device=self._device_index)
+        S, Q, h = state
+        held = ((S.indptr.copy(), S.indices.copy(), S.data.copy()), (Q.indptr.copy(), Q.indices.copy()), np.array(h, dtype=np.float64))
+        self._dev = (self._state_key(state), held, s)
+        return s
+
+    def close(self):
+        """Release the device handle (it is also released when the object is collected)."""
         if self._dev is not None:
             self._dev[2].close()
-        s = _lib.Solver(max(int(Z), 2), state, max(int(nit), 1), eta, rank_radio=self.rank_radio, dtype=self._dtype_code,
-                        device=self._device_index)
-        self._dev = (self._state_key(state), state, s)
-        return s
+            self._dev = None
 
     def run_with_state(self, bs_iteration, Z, state):
         pass

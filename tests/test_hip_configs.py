@@ -67,8 +67,11 @@ def check_invariants(s, nit_done, dtype):
     assert abs(Y.sum() - 1.0) < tol and Y.min() >= 0         # softmax weights
     L = scipy.sparse.csr_matrix((s.read(_lib.F_LVAL), ix, ip), shape=(K, K))
     assert abs(L - L.T).max() < tol * max(1e-3, abs(L).max())
+    # running sums after a FULL run of nit iterations hold nit terms each: the last Y / X are not averaged (mmw.py:77-78,203)
     ya = s.read(_lib.F_YAVG)
-    assert abs(ya.sum() - min(nit_done + 1, 10 ** 9)) < 1e-3 * (nit_done + 1) or True
+    assert abs(ya.sum() - nit_done) < 1e-3 * nit_done
+    xa = scipy.sparse.csr_matrix((s.read(_lib.F_XAVG), ix, ip), shape=(K, K))
+    assert abs(xa.diagonal().sum() - K * nit_done) < 1e-3 * K * nit_done
 
 
 @pytest.mark.parametrize("workload", ["journal-1pct", "er-1pct"])

@@ -1,0 +1,145 @@
+"""Handle life-cycle on the GPU: replay of an optimistic chunk, rebinding to another slot count, a changed step size,
+the opt-in warm start of the binary search, and the environment defaults of the drop-in class."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr, state_from
+from sig_sdp_mmw_amd import _lib
+from sig_sdp_mmw_amd.graphs import journal_graph
+from sig_sdp_mmw_amd.mmw import mmw
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = (_lib.F_XAVG, _lib.F_E_ACCU, _lib.F_LVAL, _lib.F_YAVG, _lib.F_XVAL, _lib.F_Y)
+
+
+def test_replayed_chunk_equals_the_synchronous_run(monkeypatch):
+    """Without the a-posteriori stop the a-priori Krylov order rises during the run: optimistic chunks launched with too few
+    stages are restored from their snapshot and replayed.  The result must be the run that reads the plan every iteration."""
+    monkeypatch.setenv("MMW_NO_APOST", "1")
+    state = journal_graph(8, 75e-4, seed=1)  # K = 192
+    a = _lib.Solver(12, state, 40, 0.05, dtype=_lib.F32)
+    a.iterate(40, None, seed=3)
+    got = [a.read(f) for f in FIELDS]
+    assert a.read(_lib.F_BLOCKING)[3] >= 1, "this configuration is expected to replay at least one chunk"
+    a.close()
+    monkeypatch.setenv("MMW_SYNC_PLAN", "1")
+    b = _lib.Solver(12, state, 40, 0.05, dtype=_lib.F32)
+    b.iterate(40, None, seed=3)
+    assert b.read(_lib.F_BLOCKING)[3] == 0
+    for f, x in zip(FIELDS, got):
+        # same launches in the same order once replayed -> the same bits; allow rounding-level slack for the order choice
+        assert relerr(x, b.read(f)) < 1e-6, f
+    b.close()
+
+
+@pytest.mark.parametrize("dtype", [_lib.F64, _lib.F32])
+def test_set_slots_equals_a_fresh_handle(dtype):
+    state = journal_graph(8, 75e-4, seed=2)
+    Z1, Z2, nit = 16, 9, 6
+    a = _lib.Solver(Z1, state, nit, 0.05, dtype=dtype)
+    a.iterate(nit, None, seed=11)  # dirty every buffer at the first width
+    a.set_slots(Z2, nit)
+    a.iterate(nit, None, seed=12)
+    b = _lib.Solver(Z2, state, nit, 0.05, dtype=dtype)
+    b.iterate(nit, None, seed=12)
+    assert (a.Z, a.D) == (b.Z, b.D) == (Z2, 2 * Z2)
+    assert np.array_equal(a.read(_lib.F_NORM_H), b.read(_lib.F_NORM_H))
+    for f in (_lib.F_XHALF,) + FIELDS:
+        assert np.array_equal(a.read(f), b.read(f)), f
+    K = a.K
+    assert np.array_equal(a.factor(min(K - 1, 2 * (Z2 - 1)), seed=1), b.factor(min(K - 1, 2 * (Z2 - 1)), seed=1))
+    a.close(); b.close()
+
+
+def test_set_eta_is_honoured_by_a_reused_handle():
+    state = journal_graph(8, 75e-4, seed=2)
+    a = _lib.Solver(10, state, 5, 0.05)
+    a.iterate(5, None, seed=4)
+    a.set_eta(0.11)
+    a.reset(5)
+    a.iterate(5, None, seed=4)
+    b = _lib.Solver(10, state, 5, 0.11)
+    b.iterate(5, None, seed=4)
+    for f in FIELDS:
+        assert np.array_equal(a.read(f), b.read(f)), f
+    a.close(); b.close()
+    # through the class: the reference reads self.eta on every run (mmw.py:137,167)
+    alg = mmw(nit=5, eta=0.05, rng="device", seed=1)
+    alg.run_with_state(0, 10, state)
+    alg.eta = 0.11
+    alg._runs = 0
+    alg.run_with_state(1, 10, state)
+    ref = mmw(nit=5, eta=0.11, rng="device", seed=1)
+    ref.run_with_state(0, 10, state)
+    assert np.array_equal(alg._dev[2].read(_lib.F_LVAL), ref._dev[2].read(_lib.F_LVAL))
+    # an in-place edit of the state's values must not be served from the stale device copy
+    S2 = state[0].copy()
+    S2.data[:] *= 1.5
+    alg._runs = 0
+    alg.run_with_state(2, 10, (S2, state[1], state[2]))
+    assert not np.array_equal(alg._dev[2].read(_lib.F_LVAL), ref._dev[2].read(_lib.F_LVAL))
+    alg.close(); ref.close()
+
+
+def test_warm_restart_keeps_the_iterate_and_restarts_the_sums():
+    state = journal_graph(8, 75e-4, seed=2)
+    a = _lib.Solver(12, state, 8, 0.05)
+    a.iterate(8, None, seed=4)
+    e0, l0, x0, y0 = (a.read(f) for f in (_lib.F_E_ACCU, _lib.F_LVAL, _lib.F_XVAL, _lib.F_Y))
+    a.set_slots(11, 4, warm=True)
+    assert a.iterations_done == 0 and a.Z == 11
+    assert np.array_equal(a.read(_lib.F_E_ACCU), e0) and np.array_equal(a.read(_lib.F_LVAL), l0)
+    assert np.array_equal(a.read(_lib.F_XAVG), x0) and np.array_equal(a.read(_lib.F_YAVG), y0)
+    a.iterate(4, None, seed=5)
+    assert abs(a.read(_lib.F_YAVG).sum() - 4) < 1e-9  # four terms: the kept Y and three new ones
+    a.close()
+
+
+def feasible(state, z_vec, Z):
+    S, Q, h = state
+    Sd = S.toarray()
+    np.fill_diagonal(Sd, 0)
+    for zz in range(Z):
+        mem = np.where(z_vec == zz)[0]
+        if mem.size and (np.any(Sd[np.ix_(mem, mem)].sum(axis=0) > h[mem] + 1e-12) or Q[np.ix_(mem, mem)].nnz):
+            return False
+    return True
+
+
+def test_warm_started_search_reaches_a_feasible_colouring_like_the_cold_one():
+    from sig_sdp_mmw_amd.binary_search import binary_search_relaxation
+    state = journal_graph(10, 75e-4, seed=7)  # K = 300
+    res = {}
+    for warm in (False, True):
+        bs = binary_search_relaxation()
+        bs.verbose = False
+        alg = mmw(nit=150, eta=0.04, dtype="f32", rng="device", seed=1, warm_start=warm)
+        bs.feasibility_check_alg = alg
+        np.random.seed(0)
+        z_vec, Z, rem = bs.run(state)
+        assert rem == 0 and feasible(state, z_vec, Z)
+        iters = alg.LOGGED_NP_DATA["mmw_iters"][:, 5]
+        res[warm] = (Z, iters)
+        alg.close()
+    assert np.all(res[False][1] == 150)
+    assert res[True][1][0] == 150 and np.all(res[True][1][1:] == 50)  # first probe cold, later ones a third of the iterations
+    assert abs(res[True][0] - res[False][0]) <= 1
+
+
+def test_environment_defaults_put_the_unchanged_harness_on_the_fast_path(monkeypatch):
+    monkeypatch.setenv("MMW_DTYPE", "f32")
+    monkeypatch.setenv("MMW_RNG", "device")
+    monkeypatch.setenv("MMW_EXPM_TOL", "1e-5")
+    alg = mmw(nit=20, eta=0.04)  # exactly as sim_script/journal_version/sim_mmw_time.py:34 writes it
+    assert (alg.dtype, alg.rng, alg.expm_tol, alg.round_batch) == ("f32", "device", 1e-5, True)
+    state = journal_graph(8, 75e-4, seed=1)
+    before = np.random.get_state()[2]
+    np.random.seed(1)
+    pos0 = np.random.get_state()[2]
+    ok, X_half = alg.run_with_state(0, 12, state)
+    assert np.random.get_state()[2] == pos0  # device sketches: the global NumPy stream is untouched by the loop
+    assert alg._dev[2].dtype == _lib.F32 and X_half.shape == (state[0].shape[0], 22)
+    alg.close()
+    explicit = mmw(nit=20, eta=0.04, dtype="f64", rng="host")  # explicit arguments win over the environment
+    assert (explicit.dtype, explicit.rng) == ("f64", "host")
