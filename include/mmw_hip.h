@@ -60,6 +60,8 @@ enum mmw_field {
     MMW_F_FACTOR = 14,    /* [K*rank] last factor of the averaged X (mmw.py:213-216)    */
     MMW_F_BLOCKING = 16,  /* [4]      locality blocking: in use (0/1), row blocks, nnz per staged row (reuse); [3] = batches replayed
                              because the device-side Krylov order outgrew the launched stages */
+    MMW_F_SPMM_KIND = 17, /* [2]      SpMM kernel of exp(L/2)R on this handle: 0 generic CSR gather, 1 LDS-staged full tiles, 2 half tiles,
+                             3 matrix-core (bf16 hi/lo split); [1] = 1 while the last plan allowed the matrix-core kernel */
     MMW_F_KERNEL_US = 15  /* [2*9]    per kernel class {total device us, launches} since mmw_set_profile(1):
                              spmm, sddmm, dual, loss, krylov vector ops, sketch, projection, greedy, factor */
 };

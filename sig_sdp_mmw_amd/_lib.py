@@ -16,7 +16,7 @@ EXPM_LANCZOS, EXPM_TAYLOR = 0, 1
 
 # enum mmw_field / mmw_ifield
 F_Y, F_E_ACCU, F_E_THIS, F_LVAL, F_XVAL, F_XAVG, F_YAVG, F_XHALF, F_SKETCH = range(9)
-F_S_SUM, F_NORM_H, F_ST_DATA, F_PHASE_US, F_EXPM_INFO, F_FACTOR, F_KERNEL_US, F_BLOCKING = range(9, 17)
+F_S_SUM, F_NORM_H, F_ST_DATA, F_PHASE_US, F_EXPM_INFO, F_FACTOR, F_KERNEL_US, F_BLOCKING, F_SPMM_KIND = range(9, 18)
 KERNEL_CLASSES = ["spmm", "sddmm", "dual", "loss", "krylov_vec", "sketch", "project", "greedy", "factor"]
 I_L_INDPTR, I_L_INDICES, I_ST_INDPTR, I_ST_INDICES, I_GAIN_X, I_GAIN_Y, I_ASSO_X, I_ASSO_Y, I_DIAG_POS, I_ASSO_POS = range(10)
 
@@ -168,7 +168,7 @@ class Solver:
 
     def bench_spmm(self, blocked=True, reps=20):
         us = C.c_double(0.0)
-        check(lib().mmw_bench_spmm(self._h, 1 if blocked else 0, int(reps), C.byref(us)))
+        check(lib().mmw_bench_spmm(self._h, int(blocked), int(reps), C.byref(us)))
         return us.value
 
     def reset(self, nit):
@@ -180,11 +180,15 @@ class Solver:
 
     def spmm_kernel_info(self):
         """Which SpMM kernel exp(L/2)R runs on for this handle, and what bounds it (for the benchmark's roofline record)."""
-        blocked = bool(self.read(F_BLOCKING)[0])
-        if blocked:
-            return {"name": "k_spmm_blk2 (LDS-staged locality-blocked CSR SpMM, 128-byte half tiles)",
-                    "limiter": "VALU issue + LDS latency; operands live in L2 / Infinity Cache, not HBM"}
-        return {"name": "k_spmm (generic CSR gather SpMM)", "limiter": "L2 gather rate of the dense rows"}
+        kind = int(self.read(F_SPMM_KIND, 2)[0])
+        return [
+            {"name": "k_spmm (generic CSR gather SpMM)", "limiter": "L2 gather rate of the dense rows"},
+            {"name": "k_spmm_blk (LDS-staged locality-blocked CSR SpMM, 256-byte tiles)", "limiter": "VALU issue + LDS latency"},
+            {"name": "k_spmm_blk2 (LDS-staged locality-blocked CSR SpMM, 128-byte half tiles)",
+             "limiter": "VALU issue + LDS latency; operands live in L2 / Infinity Cache, not HBM"},
+            {"name": "k_spmm_mfma (locality blocks as dense bf16 hi/lo products on the matrix cores)",
+             "limiter": "gather of the blocks' union rows into LDS at the CU's L2 rate; operands live in L2 / Infinity Cache, not HBM"},
+        ][kind]
 
     def set_slots(self, Z, nit, warm=False):
         """Rebind to another slot count on the same state (keeps pattern, blocking and device copies).
@@ -218,6 +222,8 @@ class Solver:
                 n = self.K * self.D
             elif which in (F_EXPM_INFO, F_BLOCKING):
                 n = 4
+            elif which == F_SPMM_KIND:
+                n = 2
             elif which == F_PHASE_US:
                 n = 4 * self._timed_iters()
             else:

@@ -56,6 +56,12 @@ struct HostBlocking {
     // everything it needs from its block id alone, without a chain of dependent index loads
     std::vector<int32_t> desc;
     std::vector<int32_t> un_fixed;
+    // matrix-core SpMM (k_spmm_mfma): the block's rows x union as a dense 32 x (16 * ksteps) operand in MFMA fragment order.
+    // kbase[b] = k-steps (16 union rows each) of the blocks before b; fpos[e] = position of CSR entry e in the fragment image
+    // ((kbase[b] + kstep) * 64 + lane) * 8 + j with lane = local row + 32 * ((li >> 3) & 1), j = li & 7, kstep = li >> 4.
+    bool fits_mfma = false;             // every block has at most 32 rows
+    std::vector<int32_t> kbase;         // [nb+1]
+    std::vector<int32_t> fpos;          // [nnz]
     int nb() const { return (int)blk_rowptr.size() - 1; }
 };
 
@@ -119,6 +125,7 @@ constexpr int SD2_THREADS = 1024;    // workgroup size of the half-tile SDDMM
 struct BlockingLimits {
     int max_entries_per_block;  // staged entries of the full-tile kernel
     int entry_bytes;            // sizeof one staged entry (offset + value)
+    int max_rows = BLK_ROWS;    // rows per block (32 when the matrix-core SpMM is to run on the blocks)
 };
 inline int blk2_lds_need(int nun, int64_t entries, int entry_bytes) {
     return BLK2_HEADER_BYTES + ((nun + 7) & ~7) * BLK2_ROW_BYTES + ((int)entries + 2 * 16) * entry_bytes;  // two chunks of slack: the pair prefetch reads ahead
@@ -154,7 +161,7 @@ inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& i
     B.un_cols.clear();
     std::vector<int32_t> stamp(K, -1), loc(K, 0), cur;
     int blk = 0, p = 0;
-    const int row_cap = getenv("MMW_BLK_ROWS") ? atoi(getenv("MMW_BLK_ROWS")) : BLK_ROWS;
+    const int row_cap = getenv("MMW_BLK_ROWS") ? atoi(getenv("MMW_BLK_ROWS")) : std::min(BLK_ROWS, std::max(1, lim.max_rows));
     const int row_quant = getenv("MMW_BLK_QUANT") ? atoi(getenv("MMW_BLK_QUANT")) : 1;
     while (p < K) {
         cur.clear();
@@ -382,6 +389,32 @@ inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& i
         if (blk2_lds_need(d[5], d[3], lim.entry_bytes) > BLK2_LDS_BYTES) B.fits_half_tile = false;
     }
     B.usable = B.reuse >= 2.0 && fits_full;
+    // fragment-ordered dense image of the block rows (matrix-core SpMM)
+    B.fits_mfma = true;
+    B.kbase.assign(B.nb() + 1, 0);
+    for (int b = 0; b < B.nb(); ++b) {
+        const int32_t* d = &B.desc[(size_t)b * 8];
+        if (d[1] > 32) B.fits_mfma = false;
+        B.kbase[b + 1] = B.kbase[b] + (d[5] + 15) / 16;
+    }
+    B.fpos.clear();
+    if (B.fits_mfma && (int64_t)B.kbase[B.nb()] * 512 < (int64_t)INT32_MAX) {
+        B.fpos.assign(nnz, -1);
+        std::vector<int32_t> loc2(K, -1);
+        for (int b = 0; b < B.nb(); ++b) {
+            for (int u = B.un_ptr[b]; u < B.un_ptr[b + 1]; ++u) loc2[B.un_cols[u]] = u - B.un_ptr[b];
+            for (int q = B.blk_rowptr[b]; q < B.blk_rowptr[b + 1]; ++q) {
+                const int r = B.order[q], rl = q - B.blk_rowptr[b];
+                for (int e = indptr[r]; e < indptr[r + 1]; ++e) {
+                    const int li = loc2[indices[e]];
+                    B.fpos[e] = ((B.kbase[b] + (li >> 4)) * 64 + rl + 32 * ((li >> 3) & 1)) * 8 + (li & 7);
+                }
+            }
+            for (int u = B.un_ptr[b]; u < B.un_ptr[b + 1]; ++u) loc2[B.un_cols[u]] = -1;
+        }
+    } else {
+        B.fits_mfma = false;
+    }
 }
 
 // Invariants of a built blocking, checked on the host (CPU tests, MMW_CHECK_BLOCKING=1): every row in exactly one

@@ -4,7 +4,10 @@
 #pragma once
 #include <cmath>
 
+#include <type_traits>
+
 #include "kernels_expm.h"
+#include "kernels_mfma.h"
 #include "runtime.h"
 
 namespace mmw {
@@ -122,6 +125,31 @@ inline int spmm_blk_launch(hipStream_t st, const BlkDev& B, int Dpad, const T* v
     return MMW_OK;
 }
 
+// one launch of the matrix-core SpMM (kernels_mfma.h): fp32 blocks, plain or Lanczos epilogue
+template <int MODE>
+inline int spmm_mfma_launch(hipStream_t st, const BlkDev& B, const MfmaDev& M, int Dpad, size_t plane_bytes, const char* planes, const float* in,
+                            float* out, double ascale, double shift, double* partial, double* partial_o2, const ExpmPlan* plan, int step, int* viol) {
+    const int ntiles = Dpad / 32;
+    const int grid_x = (B.nb + 7) / 8 * 8;
+#define MMW_MF_LAUNCH(NT)                                                                                                              \
+    do {                                                                                                                               \
+        static bool attr_set = false;                                                                                                  \
+        if (!attr_set) {                                                                                                               \
+            MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_mfma<MODE, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        mf_lds_bytes<NT>()));                                                                          \
+            attr_set = true;                                                                                                           \
+        }                                                                                                                              \
+        hipLaunchKernelGGL((k_spmm_mfma<MODE, NT>), dim3(grid_x, (ntiles + 4 * NT - 1) / (4 * NT)), dim3(MF_THREADS), mf_lds_bytes<NT>(), st, B, M, \
+                           Dpad, plane_bytes, planes, in, out, ascale, shift, partial, partial_o2, plan, step, viol);                  \
+    } while (0)
+    if (ntiles <= 4) MMW_MF_LAUNCH(1);
+    else if (ntiles <= 8) MMW_MF_LAUNCH(2);
+    else MMW_MF_LAUNCH(3);
+#undef MMW_MF_LAUNCH
+    MMW_HIP(hipGetLastError());
+    return MMW_OK;
+}
+
 template <typename T> struct ExpmEngine {
     hipStream_t st = nullptr;
     int K = 0;
@@ -145,6 +173,12 @@ template <typename T> struct ExpmEngine {
     BlkDev blk{};
     const T* val_blk = nullptr;
     int npart = 1;               // partial slabs one SpMM launch writes
+    // matrix-core SpMM (kernels_mfma.h): fp32 handles on a blocking with <= 32 rows per block
+    bool use_mfma = false;
+    MfmaDev mf{};
+    DevBuf<unsigned short> planes;  // bf16 hi / lo planes of the basis blocks (same bytes as the fp32 blocks)
+    bool mfma_now() const { return use_mfma && use_blk && std::is_same<T, float>::value && (lay.Dpad % 32) == 0 && last_mfma_ok; }
+    bool last_mfma_ok = true;    // what the last plan the host has seen said (the matrix starts at zero)
     T* rownorm_d = nullptr;      // optional: the combination also emits ||y_row||^2 and its per-block sums (nblk slabs)
     double* rownorm_part = nullptr;
     bool start_colsq_ready = false;  // the producer of the start block already filled `partial` with its column sums of squares (npart_start slabs)
@@ -174,6 +208,7 @@ template <typename T> struct ExpmEngine {
         nblk = grid_slabs(K);   // generic SpMM (alpha slabs)
         nwide = grid_rows(K);   // row kernels with scalar partials (1-norm bound, combination)
         ublocks = 0;
+        for (auto& r : planes_ready) r = false;
         MMW_TRY(ensure_blocks(4));  // the basis grows on demand: the MMW loop rarely needs more than 3 vectors
         MMW_TRY(Tm.alloc(bs));
         MMW_TRY(partial.alloc((size_t)MAX_PART * lay.Dpad));
@@ -218,8 +253,36 @@ template <typename T> struct ExpmEngine {
         return S;
     }
 
+    // bf16 hi / lo planes of basis block `idx` (block 0 = start block), made by a pass of their own unless the block's producer
+    // wrote them (planes_ready)
+    unsigned short* planes_of(int idx) { return planes.p + (size_t)idx * 2 * bs; }
+    bool planes_ready[MAX_ORDER + 2] = {false};
+    int make_planes(int idx) {
+        if constexpr (std::is_same<T, float>::value) {
+            if (planes.n < (size_t)ublocks * 2 * bs) {
+                MMW_HIP(hipStreamSynchronize(st));
+                MMW_TRY(planes.alloc((size_t)ublocks * 2 * bs));
+                for (auto& r : planes_ready) r = false;
+            }
+            if (planes_ready[idx]) return MMW_OK;
+            MMW_TRY(kbegin(KT_KRYLOV_VEC));
+            hipLaunchKernelGGL(k_split_planes, dim3(grid_elems(bs / 4)), dim3(BLOCK), 0, st, bs / 4, reinterpret_cast<const float4*>(block(idx)),
+                               reinterpret_cast<uint2*>(planes_of(idx)), reinterpret_cast<uint2*>(planes_of(idx) + bs));
+            MMW_HIP(hipGetLastError());
+            return kend();
+        }
+        return MMW_OK;
+    }
     template <int MODE> int launch_spmm(const T* in, T* out, T* F, double ascale, double shift, double inv_k,
-                                        const ExpmPlan* plan = nullptr, int step = 0) {
+                                        const ExpmPlan* plan = nullptr, int step = 0, const unsigned short* planes_in = nullptr) {
+        if constexpr (std::is_same<T, float>::value && (MODE == SPMM_PLAIN || MODE == SPMM_LANCZOS)) {
+            if (planes_in && mfma_now()) {
+                MMW_TRY(kbegin(KT_SPMM));
+                MMW_TRY((spmm_mfma_launch<MODE>(st, blk, mf, lay.Dpad, bs * sizeof(unsigned short), reinterpret_cast<const char*>(planes_in), in, out, ascale,
+                                                shift, partial.p, apost() ? partial_o2.p : nullptr, plan, step, viol_d.p)));
+                return kend();
+            }
+        }
         MMW_TRY(kbegin(KT_SPMM));
         if (use_blk)
             MMW_TRY((spmm_blk_launch<T, MODE>(st, blk, lay.Dpad, val_blk, in, out, F, nullptr, ascale, shift, inv_k, partial.p, plan, step,
@@ -259,6 +322,7 @@ template <typename T> struct ExpmEngine {
         MMW_HIP(hipMemcpyAsync(plan_h, plan_d.p, sizeof(ExpmPlan), hipMemcpyDeviceToHost, st));
         MMW_HIP(hipStreamSynchronize(st));
         last = *plan_h;
+        last_mfma_ok = last.mfma_ok != 0;
         if (last.overflow) return fail(MMW_ERR_STATE, "expm: the one-norm of the matrix is too large for max_order (raise max_order)");
         return MMW_OK;
     }
@@ -269,11 +333,12 @@ template <typename T> struct ExpmEngine {
         MMW_HIP(hipMemcpyAsync(&v, viol_d.p, sizeof(int), hipMemcpyDeviceToHost, st));
         MMW_HIP(hipStreamSynchronize(st));
         last = *plan_h;
+        last_mfma_ok = last.mfma_ok != 0;
         if (getenv("MMW_VERBOSE")) {
             union { unsigned u; float f; } c1, c2;
             c1.u = last.conv[1]; c2.u = last.conv[2];
-            fprintf(stderr, "[plan] rho %.3e tol %.1e m %d (a-priori %d) apost %d m_eff %d est[1] %.3e est[2] %.3e viol %d\n", last.rho, last.tol, last.m,
-                    last.m_apriori, last.apost, last.m_eff, c1.f, c2.f, v);
+            fprintf(stderr, "[plan] rho %.3e absn %.3e mfma_ok %d tol %.1e m %d (a-priori %d) apost %d m_eff %d est[1] %.3e est[2] %.3e viol %d\n", last.rho,
+                    last.absn, last.mfma_ok, last.tol, last.m, last.m_apriori, last.apost, last.m_eff, c1.f, c2.f, v);
         }
         if (violated) *violated = v;
         return MMW_OK;
@@ -311,7 +376,10 @@ template <typename T> struct ExpmEngine {
                 }
                 start_colsq_ready = false;
                 for (int j = 1; j <= m; ++j) {
-                    MMW_TRY((launch_spmm<SPMM_LANCZOS>(block(j - 1), Tm.p, nullptr, ascale, 0.0, 1.0, pd, j)));
+                    const bool mf_step = mfma_now();
+                    if (mf_step) MMW_TRY(make_planes(j - 1));
+                    MMW_TRY((launch_spmm<SPMM_LANCZOS>(block(j - 1), Tm.p, nullptr, ascale, 0.0, 1.0, pd, j, mf_step ? planes_of(j - 1) : nullptr)));
+                    planes_ready[j - 1] = false;  // consumed; the block is rewritten by the next application
                     MMW_TRY(kbegin(KT_KRYLOV_VEC));
                     // one launch: the norms of U_j, alpha_j, and after the last product the small exponentials
                     hipLaunchKernelGGL(k_lz_scalars, dim3((Dpad + LZS_COLS - 1) / LZS_COLS), dim3(1024), 0, st, npart, partial.p,

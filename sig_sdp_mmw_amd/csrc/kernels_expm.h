@@ -28,6 +28,8 @@ struct ExpmPlan {      // written by k_plan, read by every expm kernel
     int m_apriori;     // the order the a-priori bound asks for
     int apost;         // 1: the Lanczos steps carry an a-posteriori error estimate and stop as soon as it meets tol
     int m_eff;         // steps the last application actually used (written by the combination)
+    int mfma_ok;       // 1: the two-half bf16 split of the matrix-core SpMM (kernels_mfma.h) keeps the product within tol
+    double absn;       // max_i sum_j |a_ij| of the scaled matrix (the bound behind mfma_ok)
     unsigned conv[MAX_ORDER + 2];  // conv[j]: float bits of the largest per-column estimate after j steps (valid once step j's scalars ran)
 };
 // Steps that run, given the estimates of the steps <= upto that have completed.  The a-priori order is a bound from the
@@ -1333,6 +1335,9 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan(int K, int method, int ma
         p.m = m;
         p.m_apriori = m;
         p.nsub = nsub;
+        // matrix-core SpMM: ||dT||_F <= 3 * 2^-17 || |A| ||_2 ||U||_F and || |A| ||_2 <= max_i sum_j |a_ij| = max(pp, pm)
+        p.absn = pp > pm ? pp : pm;
+        p.mfma_ok = 2.3e-5 * p.absn <= tol ? 1 : 0;
         // the a-posteriori stop needs the shifted recurrence of the half-tile SpMM, a single substep and a geometric tail
         p.apost = apost && method == 0 && nsub == 1 && !p.overflow && r < 0.5;
         for (int i = 0; i < MAX_ORDER + 2; ++i) p.conv[i] = 0u;  // identity of the maximum; a step's entry is read only after its k_lz_scalars ran

@@ -8,6 +8,7 @@
 #include "blocking.h"
 #include "device_utils.h"
 #include "kernels_expm.h"
+#include "kernels_mfma.h"
 
 namespace mmw {
 
@@ -174,7 +175,8 @@ __global__ __launch_bounds__(BLOCK) void k_loss(PatternDev<T> P, const int* __re
                                                 const T* __restrict__ wH, const double* __restrict__ scal, T* __restrict__ lval,
                                                 double eta, const int* __restrict__ bpos, T* __restrict__ lval_blk,
                                                 const T* __restrict__ xval = nullptr, T* __restrict__ xavg = nullptr,
-                                                SketchArgs<T> sk = SketchArgs<T>{}, int Dpad = 0) {
+                                                SketchArgs<T> sk = SketchArgs<T>{}, int Dpad = 0, const int* __restrict__ fpos = nullptr,
+                                                unsigned* __restrict__ afrag = nullptr) {
     if ((int)blockIdx.x < sk.nblocks) {  // leading workgroups draw this iteration's sketch (same shape as k_sketch_rng: same bits)
         extern __shared__ __attribute__((aligned(16))) char smem_raw[];
         sketch_rows<T, WAVES_PER_BLOCK>(sk.K, sk.D, Dpad, sk.seed, sk.iter, sk.R, sk.colsq_part, (int)blockIdx.x, sk.nblocks,
@@ -202,6 +204,7 @@ __global__ __launch_bounds__(BLOCK) void k_loss(PatternDev<T> P, const int* __re
         const T nv = (T)((double)lval[e] - eta * add);
         lval[e] = nv;
         if (bpos) lval_blk[bpos[e]] = nv;  // the same value in the LDS-staged kernel's traversal order
+        if (fpos) afrag[fpos[e]] = split_bf16((float)nv);  // and as two bf16 halves in the matrix-core kernel's fragment order
         if (xavg) xavg[e] += xval[e];  // the previous iteration's X joins the running sum here (same index space, one pass fewer)
     }
 }
@@ -722,6 +725,11 @@ __global__ __launch_bounds__(BLOCK) void k_sketch_rng(int K, int D, int Dpad, ui
     sketch_rows<T, WAVES_PER_BLOCK>(K, D, Dpad, seed, iter, R, colsq_part, blockIdx.x, gridDim.x, reinterpret_cast<double*>(smem_raw));
 }
 
+// fragment image of the matrix-core SpMM rebuilt from the CSR values (after a snapshot restore)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_refrag(size_t n, const T* __restrict__ lval, const int* __restrict__ fpos, unsigned* __restrict__ afrag) {
+    for (size_t e = (size_t)blockIdx.x * BLOCK + threadIdx.x; e < n; e += (size_t)gridDim.x * BLOCK) afrag[fpos[e]] = split_bf16((float)lval[e]);
+}
 // xavg += xval over the whole pattern (the running sum of X; coalesced, 12 bytes per stored entry)
 template <typename T> __global__ __launch_bounds__(BLOCK) void k_accumulate(size_t n, const T* __restrict__ x, T* __restrict__ sum) {
     for (size_t o = (size_t)blockIdx.x * BLOCK + threadIdx.x; o < n; o += (size_t)gridDim.x * BLOCK) sum[o] += x[o];

@@ -36,6 +36,13 @@ struct mmw_solver {
 
 namespace {
 
+// budgets of a row block; fp32 handles cap the rows at 32 so that the matrix-core SpMM (kernels_mfma.h) can run on the blocks
+template <typename T> BlockingLimits blocking_limits() {
+    BlockingLimits lim{blk_max_entries<T>(), (int)sizeof(BlkMeta<T>)};
+    if (sizeof(T) == 4 && !getenv("MMW_NO_MFMA")) lim.max_rows = 32;
+    return lim;
+}
+
 template <typename T> struct Solver final : mmw_solver {
     int device = 0;
     bool host_only = false;
@@ -66,6 +73,9 @@ template <typename T> struct Solver final : mmw_solver {
     uint64_t sketch_done_seed = 0;
     int sketch_done_slabs = 0;
     DevBuf<T> lval_blk;
+    DevBuf<int> b_kbase, b_fpos;     // matrix-core SpMM: k-steps before each block, CSR entry -> fragment image position
+    DevBuf<unsigned> afrag;          // the matrix as bf16 hi << 16 | lo words in MFMA fragment order
+    size_t afrag_n = 0;
     int blocking_mode = 1;  // 1: use when profitable, 0: never
     // optimistic (no per-iteration readback) batches: snapshot for the rare replay
     DevBuf<T> sn_lval, sn_lblk, sn_xval, sn_xavg, sn_Y, sn_yavg, sn_eaccu;
@@ -114,14 +124,14 @@ template <typename T> struct Solver final : mmw_solver {
             if (make_layout(D, V16<T>::N, eng.lay, lerr) != MMW_OK) return fail(MMW_ERR_ARG, lerr);
             if (getenv("MMW_HOST_BLOCKING")) {  // developer aid: build the locality blocking on the host and print its statistics
                 const double t0 = tnow();
-                build_blocking(HB, K, H.l_indptr, H.l_indices, BlockingLimits{blk_max_entries<T>(), (int)sizeof(BlkMeta<T>)});
+                build_blocking(HB, K, H.l_indptr, H.l_indices, blocking_limits<T>());
                 fprintf(stderr, "[mmw] host blocking %.1f ms: usable %d half-tile %d blocks %d rows/block %.1f union/block %.1f reuse %.2f entries %lld (nnz %lld, +%.1f%% padding) sd2_rounds %d\n",
                         (tnow() - t0) * 1e3, (int)HB.usable, (int)HB.fits_half_tile, HB.nb(), (double)K / std::max(1, HB.nb()),
                         (double)HB.un_cols.size() / std::max(1, HB.nb()), HB.reuse, (long long)HB.nent, (long long)H.nnzL(),
                         100.0 * ((double)HB.nent / (double)H.nnzL() - 1.0), HB.sd2_rounds);
             }
             if (getenv("MMW_CHECK_BLOCKING")) {  // CPU tests: build the blocking and check its invariants
-                const BlockingLimits lim{blk_max_entries<T>(), (int)sizeof(BlkMeta<T>)};
+                const BlockingLimits lim = blocking_limits<T>();
                 if (HB.order.empty()) build_blocking(HB, K, H.l_indptr, H.l_indices, lim);
                 if (!HB.order.empty() && !HB.blk_rowptr.empty() && HB.blk_rowptr.back() == K) {
                     const std::string berr = verify_blocking(HB, K, H.l_indptr, H.l_indices, lim);
@@ -187,7 +197,7 @@ template <typename T> struct Solver final : mmw_solver {
         const char* env = getenv("MMW_BLOCKING");
         if (env && env[0] == '0') blocking_mode = 0;
         if (!blocking_mode) return MMW_OK;
-        build_blocking(HB, K, H.l_indptr, H.l_indices, BlockingLimits{blk_max_entries<T>(), (int)sizeof(BlkMeta<T>)});
+        build_blocking(HB, K, H.l_indptr, H.l_indices, blocking_limits<T>());
         if (getenv("MMW_VERBOSE"))
             fprintf(stderr, "[mmw] blocking: usable %d half-tile %d blocks %d rows/block %.1f union/block %.1f entries %lld (nnz %lld, +%.1f%% padding) sd_max %d\n",
                     (int)HB.usable, (int)HB.fits_half_tile, HB.nb(), (double)K / std::max(1, HB.nb()), (double)HB.un_cols.size() / std::max(1, HB.nb()),
@@ -236,6 +246,16 @@ template <typename T> struct Solver final : mmw_solver {
             MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sddmm_blk2<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         std::max(HB.un8_max * B2_ROW_BYTES, 65536)));
             sddmm_blk2 = true;
+        }
+        if (sizeof(T) == 4 && HB.fits_mfma && !getenv("MMW_NO_MFMA") && (double)K * eng.lay.Dpad * 4.0 < 4.0e9) {
+            MMW_TRY(b_kbase.upload(HB.kbase, st));
+            MMW_TRY(b_fpos.upload(HB.fpos, st));
+            afrag_n = (size_t)HB.kbase[HB.nb()] * 512;
+            MMW_TRY(afrag.alloc(afrag_n));
+            MMW_HIP(hipMemsetAsync(afrag.p, 0, afrag_n * sizeof(unsigned), st));
+            eng.use_mfma = true;
+            eng.mf.kbase = b_kbase.p;
+            eng.mf.afrag = afrag.p;
         }
         MMW_HIP(hipStreamSynchronize(st));
         extras.fac.set_blocking(blkdev(), b_bepos.p, HB.nent);
@@ -347,8 +367,10 @@ template <typename T> struct Solver final : mmw_solver {
         if (blocked && !HB.usable) return fail(MMW_ERR_STATE, "no locality blocking for this pattern");
         MMW_TRY(sync());
         hipLaunchKernelGGL((k_sketch_rng<T>), dim3(grid_rows(K)), dim3(BLOCK), 0, st, K, D, eng.lay.Dpad, 99ull, 0u, eng.start_block(), (double*)nullptr);
-        const bool keep = eng.use_blk;
+        const bool keep = eng.use_blk, keep_mf = eng.use_mfma;
         eng.use_blk = blocked != 0;
+        if (blocked == 2 && !eng.use_mfma) return fail(MMW_ERR_STATE, "no matrix-core SpMM for this handle (fp32, blocks of <= 32 rows)");
+        eng.use_mfma = blocked == 2;
         DevBuf<unsigned long long> stamps;
         const bool want_stamps = blocked && getenv("MMW_STAMPS");
         if (want_stamps) {
@@ -359,9 +381,15 @@ template <typename T> struct Solver final : mmw_solver {
         MMW_HIP(hipEventCreate(&e0));
         MMW_HIP(hipEventCreate(&e1));
         const bool lz = getenv("MMW_BENCH_LANCZOS") != nullptr;  // time the Lanczos epilogue (alpha partials) instead of the plain product
+        const unsigned short* pl = nullptr;
+        if (blocked == 2) {  // the planes are the producer's job: outside the timed launches
+            eng.planes_ready[0] = false;
+            MMW_TRY(eng.make_planes(0));
+            pl = eng.planes_of(0);
+        }
         auto one = [&]() {
-            return lz ? eng.template launch_spmm<SPMM_LANCZOS>(eng.start_block(), eng.Tm.p, nullptr, 0.5, 0.0, 1.0)
-                      : eng.template launch_spmm<SPMM_PLAIN>(eng.start_block(), eng.Tm.p, nullptr, 0.5, 0.0, 1.0);
+            return lz ? eng.template launch_spmm<SPMM_LANCZOS>(eng.start_block(), eng.Tm.p, nullptr, 0.5, 0.0, 1.0, nullptr, 0, pl)
+                      : eng.template launch_spmm<SPMM_PLAIN>(eng.start_block(), eng.Tm.p, nullptr, 0.5, 0.0, 1.0, nullptr, 0, pl);
         };
         int rc = one();  // warm
         MMW_HIP(hipEventRecord(e0, st));
@@ -375,6 +403,7 @@ template <typename T> struct Solver final : mmw_solver {
             MMW_TRY(dump_stamps(stamps.p));
         }
         eng.use_blk = keep;
+        eng.use_mfma = keep_mf;
         float ms = 0;
         MMW_HIP(hipEventElapsedTime(&ms, e0, e1));
         (void)hipEventDestroy(e0);
@@ -448,6 +477,8 @@ template <typename T> struct Solver final : mmw_solver {
         const size_t nnz = (size_t)H.nnzL(), C = (size_t)H.C();
         MMW_HIP(hipMemsetAsync(lval.p, 0, nnz * sizeof(T), st));
         if (lval_blk.p) MMW_HIP(hipMemsetAsync(lval_blk.p, 0, (size_t)HB.nent * sizeof(T), st));
+        if (afrag.p) MMW_HIP(hipMemsetAsync(afrag.p, 0, afrag_n * sizeof(unsigned), st));
+        eng.last_mfma_ok = true;
         MMW_HIP(hipMemsetAsync(xval.p, 0, nnz * sizeof(T), st));
         MMW_HIP(hipMemsetAsync(xavg.p, 0, nnz * sizeof(T), st));
         MMW_HIP(hipMemsetAsync(e_accu.p, 0, C * sizeof(T), st));
@@ -496,6 +527,10 @@ template <typename T> struct Solver final : mmw_solver {
         };
         MMW_TRY(cp(sn_lval, lval, nnz)); MMW_TRY(cp(sn_lblk, lval_blk, lval_blk.p ? (size_t)HB.nent : 0)); MMW_TRY(cp(sn_xval, xval, nnz));
         MMW_TRY(cp(sn_xavg, xavg, nnz)); MMW_TRY(cp(sn_Y, Y, C)); MMW_TRY(cp(sn_yavg, yavg, C)); MMW_TRY(cp(sn_eaccu, e_accu, C));
+        if (!save && afrag.p) {  // the fragment image follows the restored values
+            hipLaunchKernelGGL((k_refrag<T>), dim3(grid_elems(nnz)), dim3(BLOCK), 0, st, nnz, lval.p, b_fpos.p, afrag.p);
+            MMW_HIP(hipGetLastError());
+        }
         return MMW_OK;
     }
     // a batch enqueued without plan readbacks is verified here; a violated batch is replayed synchronously
@@ -606,7 +641,8 @@ template <typename T> struct Solver final : mmw_solver {
             }
             hipLaunchKernelGGL((k_loss<T>), dim3(gl + skl.nblocks), dim3(BLOCK), skl.nblocks && lz_m ? (size_t)WAVES_PER_BLOCK * Dpad * sizeof(double) : 0,
                                st, P, d_lrow.p, Y.p, wH.p, scal.p, lval.p, eta, (const int*)(eng.use_blk ? b_bpos.p : nullptr), lval_blk.p,
-                               (const T*)(xavg_deferred ? xval.p : nullptr), xavg_deferred ? xavg.p : (T*)nullptr, skl, Dpad);
+                               (const T*)(xavg_deferred ? xval.p : nullptr), xavg_deferred ? xavg.p : (T*)nullptr, skl, Dpad,
+                               (const int*)(eng.use_mfma ? b_fpos.p : nullptr), afrag.p);
             xavg_deferred = false;
             MMW_TRY(kt.end());
             MMW_TRY(record(2));
@@ -756,6 +792,12 @@ template <typename T> struct Solver final : mmw_solver {
             case MMW_F_BLOCKING: {
                 if (n != 4) return fail(MMW_ERR_ARG, "blocking info has 4 entries");
                 out[0] = eng.use_blk ? 1.0 : 0.0; out[1] = HB.usable ? HB.nb() : 0; out[2] = HB.reuse; out[3] = (double)replays;
+                return MMW_OK;
+            }
+            case MMW_F_SPMM_KIND: {
+                if (n != 2) return fail(MMW_ERR_ARG, "spmm kind has 2 entries");
+                out[0] = !eng.use_blk ? 0.0 : (eng.use_mfma ? 3.0 : (eng.blk.half_tile ? 2.0 : 1.0));
+                out[1] = eng.use_mfma && eng.last_mfma_ok ? 1.0 : 0.0;
                 return MMW_OK;
             }
             case MMW_F_FACTOR: return extras.read_factor(out, n);

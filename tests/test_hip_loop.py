@@ -228,3 +228,50 @@ def test_blocked_kernels_with_narrow_and_ragged_blocks(Z):
         s.iterate(nit, sk)
         assert relerr(s.read(_lib.F_XHALF), o.trace["X_half"][-1]) < bar, (Z, dtype)
         s.close()
+
+
+# ---- matrix-core SpMM (kernels_mfma.h): the fp32 default on locality-blocked patterns ------------------------------
+def _journal_small():
+    from sig_sdp_mmw_amd.graphs import journal_graph
+    return journal_graph(16, 0.02, seed=4)  # K = 2048, dense enough for row blocks with reuse
+
+
+@pytest.mark.parametrize("Z", [9, 24, 70])
+def test_matrix_core_spmm_matches_the_fp32_kernel_and_the_oracle(Z, monkeypatch):
+    """Dpad = 32 / 64 / 160: one, two and five column tiles (partial groups, idle waves)."""
+    state = _journal_small()
+    K, nit, eta = state[0].shape[0], 4, 0.04
+    rng = np.random.default_rng(1)
+    sk = np.stack([orc.sketch_rows(rng.standard_normal((K, 2 * Z))) for _ in range(nit)])
+    o = orc.MMWOracle(nit=nit, eta=eta)
+    o.run(Z, state, lambda i, K_, D_: sk[i], keep_trace=True, factor=False)
+    a = _lib.Solver(Z, state, nit, eta, dtype=_lib.F32)
+    kind = a.read(_lib.F_SPMM_KIND)
+    assert kind[0] == 3.0, "this pattern is expected to run on the matrix-core kernel"
+    a.iterate(nit, sk)
+    xa = a.read(_lib.F_XHALF)
+    assert relerr(xa, o.trace["X_half"][-1]) < 1e-5      # the north-star bar on exp(L/2)R
+    assert relerr(a.read(_lib.F_XVAL), o.trace["xval"][-1]) < 1e-4
+    monkeypatch.setenv("MMW_NO_MFMA", "1")
+    b = _lib.Solver(Z, state, nit, eta, dtype=_lib.F32)
+    assert b.read(_lib.F_SPMM_KIND)[0] in (1.0, 2.0)
+    b.iterate(nit, sk)
+    assert relerr(xa, b.read(_lib.F_XHALF)) < 2e-6        # same result as the fp32 LDS kernel to fp32 rounding
+    a.close(); b.close()
+
+
+def test_matrix_core_spmm_steps_aside_when_the_norm_outgrows_the_split(monkeypatch):
+    """A large step size makes max_i sum_j |a_ij| exceed what two bf16 halves resolve within the tolerance: the plan says so,
+    the optimistic chunk is replayed, and the run continues on the fp32 kernel -- same result as never using the matrix cores."""
+    state = _journal_small()
+    Z, nit, eta = 12, 24, 2.0
+    a = _lib.Solver(Z, state, nit, eta, dtype=_lib.F32)
+    a.iterate(nit, None, seed=5)
+    xa = a.read(_lib.F_XHALF)
+    assert a.read(_lib.F_SPMM_KIND)[1] == 0.0, "the last plan is expected to have ruled the matrix-core kernel out"
+    monkeypatch.setenv("MMW_NO_MFMA", "1")
+    b = _lib.Solver(Z, state, nit, eta, dtype=_lib.F32)
+    b.iterate(nit, None, seed=5)
+    assert relerr(xa, b.read(_lib.F_XHALF)) < 1e-5
+    assert relerr(a.read(_lib.F_LVAL), b.read(_lib.F_LVAL)) < 1e-5
+    a.close(); b.close()
