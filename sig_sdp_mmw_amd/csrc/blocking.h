@@ -23,6 +23,8 @@ constexpr int BLK_UNION = MMW_BLK_UNION;      // rows of the staged tile (448 x 
 constexpr int BLK_ROWS = 64;        // max matrix rows per block
 constexpr int BLK_META_BYTES = MMW_BLK_META;  // LDS bytes for the block's (local index, value) entries
 constexpr int BLK_CHUNK = 16;       // entries per wave step (4 lane groups x 4); rows are padded to this
+constexpr int MF_UNION = 640;       // union columns of a matrix-core block (its LDS holds 16 of them at a time, not all)
+constexpr int MF_KSTEP_PAD = 2;     // a block's 16-row k-steps are padded to a multiple of this in the fragment image (== MF_KPAD)
 
 struct HostBlocking {
     bool usable = false;
@@ -57,11 +59,18 @@ struct HostBlocking {
     std::vector<int32_t> desc;
     std::vector<int32_t> un_fixed;
     // matrix-core SpMM (k_spmm_mfma): the block's rows x union as a dense 32 x (16 * ksteps) operand in MFMA fragment order.
-    // kbase[b] = k-steps (16 union rows each) of the blocks before b; fpos[e] = position of CSR entry e in the fragment image
-    // ((kbase[b] + kstep) * 64 + lane) * 8 + j with lane = local row + 32 * ((li >> 3) & 1), j = li & 7, kstep = li >> 4.
-    bool fits_mfma = false;             // every block has at most 32 rows
-    std::vector<int32_t> kbase;         // [nb+1]
+    // kbase[b] = k-steps (16 union rows each) of the blocks before b; fpos[e] = position (32-bit words) of CSR entry e in the
+    // fragment image [k-step][row tile][half j >> 2][lane][j & 3], lane = (local row & 31) + 32 * ((li >> 3) & 1), j = li & 7.
+    bool fits_mfma = false;
+    int mfma_mt = 1;                    // row tiles of 32 per block (2 when some block has more than 32 rows)
+    std::vector<int32_t> kbase;         // [nbm+1]
     std::vector<int32_t> fpos;          // [nnz]
+    // The matrix-core kernel has no per-entry LDS budget, so it runs on row blocks of its own: up to 64 rows grown the same
+    // way (fewer, larger patches: each staged union row serves ~2x the nonzeros).  m_* mirror order / blk_rowptr / desc / un_fixed.
+    std::vector<int32_t> m_order, m_rowptr, m_desc, m_unfixed;
+    std::vector<int32_t> rcm_cache;     // the RCM order both blockings start from
+    double m_reuse = 0.0;
+    int nbm() const { return (int)m_rowptr.size() - 1; }
     int nb() const { return (int)blk_rowptr.size() - 1; }
 };
 
@@ -125,7 +134,6 @@ constexpr int SD2_THREADS = 1024;    // workgroup size of the half-tile SDDMM
 struct BlockingLimits {
     int max_entries_per_block;  // staged entries of the full-tile kernel
     int entry_bytes;            // sizeof one staged entry (offset + value)
-    int max_rows = BLK_ROWS;    // rows per block (32 when the matrix-core SpMM is to run on the blocks)
 };
 inline int blk2_lds_need(int nun, int64_t entries, int entry_bytes) {
     return BLK2_HEADER_BYTES + ((nun + 7) & ~7) * BLK2_ROW_BYTES + ((int)entries + 2 * 16) * entry_bytes;  // two chunks of slack: the pair prefetch reads ahead
@@ -161,7 +169,7 @@ inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& i
     B.un_cols.clear();
     std::vector<int32_t> stamp(K, -1), loc(K, 0), cur;
     int blk = 0, p = 0;
-    const int row_cap = getenv("MMW_BLK_ROWS") ? atoi(getenv("MMW_BLK_ROWS")) : std::min(BLK_ROWS, std::max(1, lim.max_rows));
+    const int row_cap = getenv("MMW_BLK_ROWS") ? atoi(getenv("MMW_BLK_ROWS")) : BLK_ROWS;
     const int row_quant = getenv("MMW_BLK_QUANT") ? atoi(getenv("MMW_BLK_QUANT")) : 1;
     while (p < K) {
         cur.clear();
@@ -389,32 +397,97 @@ inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& i
         if (blk2_lds_need(d[5], d[3], lim.entry_bytes) > BLK2_LDS_BYTES) B.fits_half_tile = false;
     }
     B.usable = B.reuse >= 2.0 && fits_full;
-    // fragment-ordered dense image of the block rows (matrix-core SpMM)
-    B.fits_mfma = true;
-    B.kbase.assign(B.nb() + 1, 0);
-    for (int b = 0; b < B.nb(); ++b) {
-        const int32_t* d = &B.desc[(size_t)b * 8];
-        if (d[1] > 32) B.fits_mfma = false;
-        B.kbase[b + 1] = B.kbase[b] + (d[5] + 15) / 16;
-    }
-    B.fpos.clear();
-    if (B.fits_mfma && (int64_t)B.kbase[B.nb()] * 512 < (int64_t)INT32_MAX) {
-        B.fpos.assign(nnz, -1);
-        std::vector<int32_t> loc2(K, -1);
-        for (int b = 0; b < B.nb(); ++b) {
-            for (int u = B.un_ptr[b]; u < B.un_ptr[b + 1]; ++u) loc2[B.un_cols[u]] = u - B.un_ptr[b];
-            for (int q = B.blk_rowptr[b]; q < B.blk_rowptr[b + 1]; ++q) {
-                const int r = B.order[q], rl = q - B.blk_rowptr[b];
-                for (int e = indptr[r]; e < indptr[r + 1]; ++e) {
-                    const int li = loc2[indices[e]];
-                    B.fpos[e] = ((B.kbase[b] + (li >> 4)) * 64 + rl + 32 * ((li >> 3) & 1)) * 8 + (li & 7);
+    B.rcm_cache = rcm;
+}
+
+// Row blocks for the matrix-core SpMM (kernels_mfma.h): grown like the blocks above (seed = next unassigned row of the RCM
+// order, then always the unassigned union member that brings the fewest new columns), bounded only by the union size and
+// `max_rows` (32 or 64).  Fills m_order / m_rowptr / m_desc {q0, rows, 0, 0, 0, union size, 0, 0} / m_unfixed, kbase and fpos.
+inline void build_mfma_blocking(HostBlocking& B, int K, const std::vector<int32_t>& indptr, const std::vector<int32_t>& indices, int max_rows) {
+    const int64_t nnz = indptr[K];
+    B.fits_mfma = false;
+    if (B.rcm_cache.size() != (size_t)K) return;
+    for (int k = 0; k < K; ++k)
+        if (indptr[k + 1] - indptr[k] > MF_UNION) return;
+    const std::vector<int32_t>& rcm = B.rcm_cache;
+    std::vector<int32_t> rank(K);
+    for (int p = 0; p < K; ++p) rank[rcm[p]] = p;
+    B.m_order.assign(K, -1);
+    B.m_rowptr.assign(1, 0);
+    std::vector<int32_t> un_ptr(1, 0), un_cols;
+    std::vector<char> assigned(K, 0);
+    std::vector<int32_t> stamp(K, -1), in_union(K, 0), in_stamp(K, -1), cur;
+    int seed_pos = 0, p = 0, blk = 0;
+    while (p < K) {
+        cur.clear();
+        while (assigned[rcm[seed_pos]]) ++seed_pos;
+        int r = rcm[seed_pos], rows = 0;
+        while (p < K && rows < max_rows) {
+            int fresh = 0;
+            for (int e = indptr[r]; e < indptr[r + 1]; ++e)
+                if (stamp[indices[e]] != blk) ++fresh;
+            if (rows > 0 && (int)cur.size() + fresh > MF_UNION) break;
+            for (int e = indptr[r]; e < indptr[r + 1]; ++e) {
+                const int c = indices[e];
+                if (stamp[c] != blk) {
+                    stamp[c] = blk;
+                    cur.push_back(c);
+                    for (int f = indptr[c]; f < indptr[c + 1]; ++f) {
+                        const int v = indices[f];
+                        if (in_stamp[v] != blk) { in_stamp[v] = blk; in_union[v] = 0; }
+                        ++in_union[v];
+                    }
                 }
             }
-            for (int u = B.un_ptr[b]; u < B.un_ptr[b + 1]; ++u) loc2[B.un_cols[u]] = -1;
+            assigned[r] = 1;
+            B.m_order[p++] = r;
+            ++rows;
+            int best = -1, best_fresh = INT32_MAX;
+            for (int c : cur)
+                if (!assigned[c]) {
+                    const int fr = (indptr[c + 1] - indptr[c]) - (in_stamp[c] == blk ? in_union[c] : 0);
+                    if (fr < best_fresh || (fr == best_fresh && rank[c] < rank[best])) { best_fresh = fr; best = c; }
+                }
+            if (best < 0) break;
+            r = best;
         }
-    } else {
-        B.fits_mfma = false;
+        std::sort(cur.begin(), cur.end(), [&](int a, int b) { return rank[a] < rank[b]; });
+        un_cols.insert(un_cols.end(), cur.begin(), cur.end());
+        un_ptr.push_back((int32_t)un_cols.size());
+        B.m_rowptr.push_back(p);
+        ++blk;
     }
+    const int nbm = B.nbm();
+    B.m_reuse = un_cols.empty() ? 0.0 : (double)nnz / (double)un_cols.size();
+    B.mfma_mt = 1;
+    B.m_desc.assign((size_t)nbm * 8, 0);
+    B.m_unfixed.assign((size_t)nbm * MF_UNION, 0);
+    B.kbase.assign(nbm + 1, 0);
+    for (int b = 0; b < nbm; ++b) {
+        const int nun = un_ptr[b + 1] - un_ptr[b], rows = B.m_rowptr[b + 1] - B.m_rowptr[b];
+        int32_t* d = &B.m_desc[(size_t)b * 8];
+        d[0] = B.m_rowptr[b]; d[1] = rows; d[5] = nun;
+        if (rows > 32) B.mfma_mt = 2;
+        for (int u = 0; u < MF_UNION; ++u) B.m_unfixed[(size_t)b * MF_UNION + u] = un_cols[un_ptr[b] + (u < nun ? u : 0)];
+        B.kbase[b + 1] = B.kbase[b] + ((nun + 15) / 16 + MF_KSTEP_PAD - 1) / MF_KSTEP_PAD * MF_KSTEP_PAD;
+    }
+    if ((int64_t)B.kbase[nbm] * B.mfma_mt * 512 >= (int64_t)INT32_MAX || B.m_reuse < 2.0) return;
+    const int MT = B.mfma_mt;
+    B.fpos.assign(nnz, -1);
+    std::vector<int32_t> loc2(K, -1);
+    for (int b = 0; b < nbm; ++b) {
+        for (int u = un_ptr[b]; u < un_ptr[b + 1]; ++u) loc2[un_cols[u]] = u - un_ptr[b];
+        for (int q = B.m_rowptr[b]; q < B.m_rowptr[b + 1]; ++q) {
+            const int r = B.m_order[q], rl = q - B.m_rowptr[b];
+            for (int e = indptr[r]; e < indptr[r + 1]; ++e) {
+                const int li = loc2[indices[e]];
+                const int ks = li >> 4, j = li & 7, lane = (rl & 31) + 32 * ((li >> 3) & 1), mt = rl >> 5;
+                B.fpos[e] = ((((B.kbase[b] + ks) * MT + mt) * 2 + (j >> 2)) * 64 + lane) * 4 + (j & 3);
+            }
+        }
+        for (int u = un_ptr[b]; u < un_ptr[b + 1]; ++u) loc2[un_cols[u]] = -1;
+    }
+    B.fits_mfma = true;
 }
 
 // Invariants of a built blocking, checked on the host (CPU tests, MMW_CHECK_BLOCKING=1): every row in exactly one
@@ -440,7 +513,7 @@ inline std::string verify_blocking(const HostBlocking& B, int K, const std::vect
     int64_t slots_used = 0;
     for (int b = 0; b < B.nb(); ++b) {
         const int u0 = B.un_ptr[b], u1 = B.un_ptr[b + 1], nun = u1 - u0;
-        if (nun < 1 || nun > BLK_UNION) return "union size out of range";
+        if (nun < 1 || nun > MF_UNION) return "union size out of range";
         for (int u = u0; u < u1; ++u) {
             if (local[B.un_cols[u]] >= 0) return "duplicate column in a union";
             local[B.un_cols[u]] = u - u0;
@@ -506,6 +579,56 @@ inline std::string verify_blocking(const HostBlocking& B, int K, const std::vect
     for (int64_t e = 0; e < nnz; ++e)
         if (!ent_seen[e]) return "a CSR entry is missing from the blocked arrays";
     if (slots_used != nupper) return "the SDDMM slots do not hold every upper-triangular entry exactly once";
+    return "";
+}
+
+// Invariants of the matrix-core blocking: every row in exactly one block of at most 64 rows; a block's padded union list holds
+// every column of its rows; fpos maps the CSR entries one-to-one into the fragment image, at the lane / word the A operand
+// map of v_mfma_f32_32x32x16_bf16 prescribes for (local row, local union index).
+inline std::string verify_mfma_blocking(const HostBlocking& B, int K, const std::vector<int32_t>& indptr, const std::vector<int32_t>& indices) {
+    const int64_t nnz = indptr[K];
+    if (!B.fits_mfma) return "";
+    const int nbm = B.nbm(), MT = B.mfma_mt;
+    if ((int)B.m_order.size() != K || B.m_rowptr.front() != 0 || B.m_rowptr.back() != K) return "matrix-core blocks do not cover the rows";
+    std::vector<char> seen(K, 0);
+    for (int p = 0; p < K; ++p) {
+        const int r = B.m_order[p];
+        if (r < 0 || r >= K || seen[r]) return "matrix-core order is not a permutation";
+        seen[r] = 1;
+    }
+    const int64_t image = (int64_t)B.kbase[nbm] * MT * 512;
+    std::vector<char> used((size_t)image, 0);
+    std::vector<int32_t> loc(K, -1);
+    for (int b = 0; b < nbm; ++b) {
+        const int32_t* d = &B.m_desc[(size_t)b * 8];
+        const int rows = d[1], nun = d[5];
+        if (d[0] != B.m_rowptr[b] || rows != B.m_rowptr[b + 1] - B.m_rowptr[b] || rows < 1 || rows > 32 * MT) return "matrix-core block record mismatch";
+        if (nun < 1 || nun > MF_UNION || B.kbase[b + 1] - B.kbase[b] != ((nun + 15) / 16 + MF_KSTEP_PAD - 1) / MF_KSTEP_PAD * MF_KSTEP_PAD) return "matrix-core union size / k-step count mismatch";
+        for (int u = 0; u < nun; ++u) {
+            const int c = B.m_unfixed[(size_t)b * MF_UNION + u];
+            if (c < 0 || c >= K || loc[c] >= 0) return "matrix-core union list has a bad or repeated column";
+            loc[c] = u;
+        }
+        for (int u = nun; u < MF_UNION; ++u)
+            if (B.m_unfixed[(size_t)b * MF_UNION + u] != B.m_unfixed[(size_t)b * MF_UNION]) return "matrix-core union padding is not the first column";
+        for (int q = B.m_rowptr[b]; q < B.m_rowptr[b + 1]; ++q) {
+            const int r = B.m_order[q], rl = q - B.m_rowptr[b];
+            for (int e = indptr[r]; e < indptr[r + 1]; ++e) {
+                const int li = loc[indices[e]];
+                if (li < 0) return "a column of a matrix-core block is missing from its union";
+                const int64_t f = B.fpos[e];
+                if (f < (int64_t)B.kbase[b] * MT * 512 || f >= (int64_t)B.kbase[b + 1] * MT * 512 || used[(size_t)f]) return "fpos out of its block or repeated";
+                used[(size_t)f] = 1;
+                const int w = (int)(f & 3), lane = (int)((f >> 2) & 63), half = (int)((f >> 8) & 1);
+                const int64_t tile = f >> 9;  // (k-step, row tile)
+                const int mt = (int)(tile % MT), ks = (int)(tile / MT) - B.kbase[b];
+                if (mt != rl / 32 || (lane & 31) != rl % 32 || ks * 16 + 8 * (lane >> 5) + 4 * half + w != li) return "fpos does not address (row, union index) in the A operand map";
+            }
+        }
+        for (int u = 0; u < nun; ++u) loc[B.m_unfixed[(size_t)b * MF_UNION + u]] = -1;
+    }
+    for (int64_t e = 0; e < nnz; ++e)
+        if (B.fpos[e] < 0) return "a CSR entry has no fragment position";
     return "";
 }
 

@@ -125,26 +125,59 @@ inline int spmm_blk_launch(hipStream_t st, const BlkDev& B, int Dpad, const T* v
     return MMW_OK;
 }
 
-// one launch of the matrix-core SpMM (kernels_mfma.h): fp32 blocks, plain or Lanczos epilogue
+inline unsigned long long* g_mf_stamps = nullptr;  // diagnostic runs only: per-wave phase clocks of the matrix-core SpMM
+// one launch of the matrix-core SpMM (kernels_mfma.h): fp32 blocks, plain or Lanczos epilogue.  A workgroup takes a row block
+// and a group of GT column tiles; the group is as wide as still gives the chip ~1.5 workgroups per CU (narrower groups re-read
+// the block's A fragments once per group).
 template <int MODE>
-inline int spmm_mfma_launch(hipStream_t st, const BlkDev& B, const MfmaDev& M, int Dpad, size_t plane_bytes, const char* planes, const float* in,
+inline int spmm_mfma_launch(hipStream_t st, const MfmaDev& M, int mt, int Dpad, size_t plane_bytes, const char* planes, const float* in,
                             float* out, double ascale, double shift, double* partial, double* partial_o2, const ExpmPlan* plan, int step, int* viol) {
     const int ntiles = Dpad / 32;
-    const int grid_x = (B.nb + 7) / 8 * 8;
-#define MMW_MF_LAUNCH(NT)                                                                                                              \
+    const int grid_x = (M.nb + 7) / 8 * 8;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    }
+#define MMW_MF_LAUNCH(MT, NT, NW, MS, KC, NB)                                                                                          \
     do {                                                                                                                               \
         static bool attr_set = false;                                                                                                  \
+        constexpr int gtw = (NW / MS) * NT;                                                                                            \
+        constexpr int lds_bytes = mf_lds_bytes<MT, gtw, KC, NB>();                                                                     \
         if (!attr_set) {                                                                                                               \
-            MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_mfma<MODE, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                        mf_lds_bytes<NT>()));                                                                          \
+            MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_mfma<MODE, MT, NT, NW, MS, KC, NB>),                     \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));                                       \
             attr_set = true;                                                                                                           \
         }                                                                                                                              \
-        hipLaunchKernelGGL((k_spmm_mfma<MODE, NT>), dim3(grid_x, (ntiles + 4 * NT - 1) / (4 * NT)), dim3(MF_THREADS), mf_lds_bytes<NT>(), st, B, M, \
-                           Dpad, plane_bytes, planes, in, out, ascale, shift, partial, partial_o2, plan, step, viol);                  \
+        hipLaunchKernelGGL((k_spmm_mfma<MODE, MT, NT, NW, MS, KC, NB>), dim3(grid_x, (ntiles + gtw - 1) / gtw), dim3(NW * 64),         \
+                           lds_bytes, st, M, Dpad, plane_bytes, planes, in, out, ascale, shift, partial, partial_o2,                   \
+                           plan, step, viol, g_mf_stamps);                                                                             \
     } while (0)
-    if (ntiles <= 4) MMW_MF_LAUNCH(1);
-    else if (ntiles <= 8) MMW_MF_LAUNCH(2);
-    else MMW_MF_LAUNCH(3);
+    int gt = 12;  // column tiles per workgroup: 12, 8 or 4
+    static const int gt_env = getenv("MMW_MF_GT") ? atoi(getenv("MMW_MF_GT")) : 0;
+    if (gt_env) gt = gt_env;
+    else {
+        auto wgs = [&](int g) { return (long)M.nb * ((ntiles + g - 1) / g); };
+        if (wgs(12) * 2 < 3L * cus) gt = 8;
+        if (gt == 8 && wgs(8) * 2 < 3L * cus) gt = 4;
+    }
+    if (ntiles <= 4) gt = 4;
+    else if (ntiles <= 8 && gt > 8) gt = 8;
+    static const int cfg = getenv("MMW_MF_CFG") ? atoi(getenv("MMW_MF_CFG")) : 0;  // experiments
+    // (row tiles, column tiles per wave, waves, row-tile groups of waves, k-steps per chunk, chunks resident).  Measured at the
+    // benchmark (159 blocks of 63 rows, 12 column tiles): 8 waves with the two row tiles on different waves, 2 k-steps per barrier,
+    // 2 chunks resident (three workgroups per CU) 22.6 us; 4 waves 26.0; 3 chunks resident 25.9; 1 k-step per barrier 33.4;
+    // 8 / 12 column tiles per workgroup 36.7 / 48.0 (too few workgroups for 256 CUs).
+    if (mt == 1) {
+        if (gt == 4) { if (cfg == 1) MMW_MF_LAUNCH(1, 1, 4, 1, 2, 3); else MMW_MF_LAUNCH(1, 1, 4, 1, 2, 2); }
+        else if (gt == 8) MMW_MF_LAUNCH(1, 2, 4, 1, 2, 2);
+        else MMW_MF_LAUNCH(1, 3, 4, 1, 1, 3);
+    } else {
+        if (gt == 4) { if (cfg == 1) MMW_MF_LAUNCH(2, 1, 4, 1, 2, 2); else if (cfg == 4) MMW_MF_LAUNCH(2, 1, 8, 2, 2, 3); else MMW_MF_LAUNCH(2, 1, 8, 2, 2, 2); }
+        else if (gt == 8) MMW_MF_LAUNCH(2, 2, 8, 2, 2, 2);
+        else MMW_MF_LAUNCH(2, 3, 4, 1, 1, 3);
+    }
 #undef MMW_MF_LAUNCH
     MMW_HIP(hipGetLastError());
     return MMW_OK;
@@ -176,8 +209,10 @@ template <typename T> struct ExpmEngine {
     // matrix-core SpMM (kernels_mfma.h): fp32 handles on a blocking with <= 32 rows per block
     bool use_mfma = false;
     MfmaDev mf{};
+    int mf_mt = 1;               // row tiles of 32 per block
     DevBuf<unsigned short> planes;  // bf16 hi / lo planes of the basis blocks (same bytes as the fp32 blocks)
     bool mfma_now() const { return use_mfma && use_blk && std::is_same<T, float>::value && (lay.Dpad % 32) == 0 && last_mfma_ok; }
+    int spmm_slabs() const { return mfma_now() ? mf.nb : npart; }  // partial slabs the next SpMM launch writes
     bool last_mfma_ok = true;    // what the last plan the host has seen said (the matrix starts at zero)
     T* rownorm_d = nullptr;      // optional: the combination also emits ||y_row||^2 and its per-block sums (nblk slabs)
     double* rownorm_part = nullptr;
@@ -257,13 +292,22 @@ template <typename T> struct ExpmEngine {
     // wrote them (planes_ready)
     unsigned short* planes_of(int idx) { return planes.p + (size_t)idx * 2 * bs; }
     bool planes_ready[MAX_ORDER + 2] = {false};
+    int ensure_planes() {
+        if (planes.n < (size_t)ublocks * 2 * bs) {
+            MMW_HIP(hipStreamSynchronize(st));
+            MMW_TRY(planes.alloc((size_t)ublocks * 2 * bs));
+            for (auto& r : planes_ready) r = false;
+        }
+        return MMW_OK;
+    }
+    // where the producer of the start block should write its planes (nullptr: the next product does not run on the matrix cores)
+    unsigned short* start_planes() {
+        if (!mfma_now() || ensure_planes() != MMW_OK) return nullptr;
+        return planes_of(0);
+    }
     int make_planes(int idx) {
         if constexpr (std::is_same<T, float>::value) {
-            if (planes.n < (size_t)ublocks * 2 * bs) {
-                MMW_HIP(hipStreamSynchronize(st));
-                MMW_TRY(planes.alloc((size_t)ublocks * 2 * bs));
-                for (auto& r : planes_ready) r = false;
-            }
+            MMW_TRY(ensure_planes());
             if (planes_ready[idx]) return MMW_OK;
             MMW_TRY(kbegin(KT_KRYLOV_VEC));
             hipLaunchKernelGGL(k_split_planes, dim3(grid_elems(bs / 4)), dim3(BLOCK), 0, st, bs / 4, reinterpret_cast<const float4*>(block(idx)),
@@ -278,7 +322,7 @@ template <typename T> struct ExpmEngine {
         if constexpr (std::is_same<T, float>::value && (MODE == SPMM_PLAIN || MODE == SPMM_LANCZOS)) {
             if (planes_in && mfma_now()) {
                 MMW_TRY(kbegin(KT_SPMM));
-                MMW_TRY((spmm_mfma_launch<MODE>(st, blk, mf, lay.Dpad, bs * sizeof(unsigned short), reinterpret_cast<const char*>(planes_in), in, out, ascale,
+                MMW_TRY((spmm_mfma_launch<MODE>(st, mf, mf_mt, lay.Dpad, bs * sizeof(unsigned short), reinterpret_cast<const char*>(planes_in), in, out, ascale,
                                                 shift, partial.p, apost() ? partial_o2.p : nullptr, plan, step, viol_d.p)));
                 return kend();
             }
@@ -382,7 +426,7 @@ template <typename T> struct ExpmEngine {
                     planes_ready[j - 1] = false;  // consumed; the block is rewritten by the next application
                     MMW_TRY(kbegin(KT_KRYLOV_VEC));
                     // one launch: the norms of U_j, alpha_j, and after the last product the small exponentials
-                    hipLaunchKernelGGL(k_lz_scalars, dim3((Dpad + LZS_COLS - 1) / LZS_COLS), dim3(1024), 0, st, npart, partial.p,
+                    hipLaunchKernelGGL(k_lz_scalars, dim3((Dpad + LZS_COLS - 1) / LZS_COLS), dim3(1024), 0, st, mf_step ? mf.nb : npart, partial.p,
                                        apost() ? partial_o2.p : (double*)nullptr, nsq, partial_sq.p, Dpad, j, m,
                                        1.0 / nsub, eps, S, pd);
                     if (kt && kt->on && apost() && j < m) {  // profiling counts exact launches: look at the estimate before going on
@@ -395,8 +439,11 @@ template <typename T> struct ExpmEngine {
                         MMW_TRY(kbegin(KT_KRYLOV_VEC));
                     }
                     if (j < m) {  // the last product A U_m goes straight into the combination (corrected scheme)
+                        unsigned short* pl_next = nullptr;  // U_{j+1} lives in block j
+                        if (mf_step && ensure_planes() == MMW_OK && j < ublocks) pl_next = planes_of(j);
                         hipLaunchKernelGGL((k_lz_update<T>), dim3(gr), dim3(BLOCK), shcol, st, K, Dpad, j, Tm.p, block(j - 1),
-                                           j > 1 ? block(j - 2) : block(j - 1), block(j), S, partial_sq.p, pd);
+                                           j > 1 ? block(j - 2) : block(j - 1), block(j), S, partial_sq.p, pd, pl_next);
+                        planes_ready[j] = pl_next != nullptr;
                         nsq = gr;
                     }
                     MMW_TRY(kend());

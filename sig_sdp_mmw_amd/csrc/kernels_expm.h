@@ -881,7 +881,8 @@ __global__ __launch_bounds__(1024) void k_colreduce(int nb, int Dpad, const doub
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_lz_update(int K, int Dpad, int j, const T* __restrict__ Tm, const T* __restrict__ Uj,
                                                      const T* __restrict__ Ujm1, T* __restrict__ Unext, LanczosScalars S,
-                                                     double* __restrict__ partial, const ExpmPlan* __restrict__ plan) {
+                                                     double* __restrict__ partial, const ExpmPlan* __restrict__ plan,
+                                                     unsigned short* __restrict__ planes = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     if (plan && j >= plan_steps(plan, j)) return;  // U_{m+1} is never formed: the last product feeds the combination directly
     double* sh = reinterpret_cast<double*>(smem_raw);  // [BLOCK]
@@ -900,6 +901,13 @@ __global__ __launch_bounds__(BLOCK) void k_lz_update(int K, int Dpad, int j, con
                 if (j > 1) w -= c3 * (double)Ujm1[o];
                 const T wt = (T)w;
                 Unext[o] = wt;
+                if (planes) {  // fp32 handles: the next product reads U_{j+1} as two bf16 halves (kernels_mfma.h)
+                    const float wf = (float)wt;
+                    const unsigned short hi = __builtin_bit_cast(unsigned short, (__bf16)wf);
+                    const unsigned short lo = __builtin_bit_cast(unsigned short, (__bf16)(wf - __uint_as_float((unsigned)hi << 16)));
+                    planes[o] = hi;
+                    planes[(size_t)K * Dpad + o] = lo;
+                }
                 s += (double)wt * (double)wt;
             }
         }

@@ -38,10 +38,12 @@ template <typename T> struct SketchArgs {
     uint32_t iter;
     T* R;
     double* colsq_part;
+    unsigned short* planes;  // optional (fp32 only): bf16 hi plane, then the lo plane K * Dpad elements further (kernels_mfma.h)
 };
 template <typename T, int NWAVES>
 __device__ __forceinline__ void sketch_rows(int K, int D, int Dpad, uint64_t seed, uint32_t iter, T* __restrict__ R,
-                                            double* __restrict__ colsq_part, int bid, int nblocks, double* shc);
+                                            double* __restrict__ colsq_part, int bid, int nblocks, double* shc,
+                                            unsigned short* __restrict__ planes = nullptr);
 
 // ---- DUAL, step 1: per row r[k] = sum of off-diagonal X, eD; per pair eF -------------------------
 template <typename T>
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(BLOCK) void k_loss(PatternDev<T> P, const int* __re
     if ((int)blockIdx.x < sk.nblocks) {  // leading workgroups draw this iteration's sketch (same shape as k_sketch_rng: same bits)
         extern __shared__ __attribute__((aligned(16))) char smem_raw[];
         sketch_rows<T, WAVES_PER_BLOCK>(sk.K, sk.D, Dpad, sk.seed, sk.iter, sk.R, sk.colsq_part, (int)blockIdx.x, sk.nblocks,
-                                        reinterpret_cast<double*>(smem_raw));
+                                        reinterpret_cast<double*>(smem_raw), sk.planes);
         return;
     }
     const int bid = (int)blockIdx.x - sk.nblocks, nb = (int)gridDim.x - sk.nblocks;
@@ -492,7 +494,7 @@ void k_sddmm_blk2(BlkDev B, Sd2Dev S, PatternDev<T> P, int Dpad, int ntiles,
         const int grid_sd = (S.nitems + 7) / 8 * 8;
         if ((int)blockIdx.x >= grid_sd) {  // appended sketch workgroups (dispatched last: they fill the slots the items leave)
             sketch_rows<T, SD2_THREADS / WAVE>(sk.K, sk.D, Dpad, sk.seed, sk.iter, sk.R, sk.colsq_part, (int)blockIdx.x - grid_sd, sk.nblocks,
-                                               reinterpret_cast<double*>(smem_raw));
+                                               reinterpret_cast<double*>(smem_raw), sk.planes);
             return;
         }
     }
@@ -652,7 +654,8 @@ __device__ __forceinline__ void normals16(const uint32_t (&w)[4], double (&n)[2]
 // `bid` of `nblocks` workgroups, `shc` = NWAVES x Dpad doubles of LDS when colsq_part)
 template <typename T, int NWAVES>
 __device__ __forceinline__ void sketch_rows(int K, int D, int Dpad, uint64_t seed, uint32_t iter, T* __restrict__ R,
-                                            double* __restrict__ colsq_part, int bid, int nblocks, double* shc) {
+                                            double* __restrict__ colsq_part, int bid, int nblocks, double* shc,
+                                            unsigned short* __restrict__ planes) {
     constexpr int VEC = V16<T>::N;
     constexpr int NS = 4;  // 64 lanes x 4 steps x 16 B covers Dpad <= 1024 floats / 512 doubles
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -697,6 +700,14 @@ __device__ __forceinline__ void sketch_rows(int K, int D, int Dpad, uint64_t see
                     csq[i][v] += n[i][v] * n[i][v];
                 }
                 store16(R + (size_t)row * Dpad + (size_t)p * VEC, n[i]);
+                if constexpr (sizeof(T) == 4) {
+                    if (planes) {  // the matrix-core SpMM reads the block as two bf16 halves: made here, while the values are in registers
+                        const unsigned a = split_bf16(n[i][0]), b = split_bf16(n[i][1]), c = split_bf16(n[i][2]), d = split_bf16(n[i][3]);
+                        const size_t o = ((size_t)row * Dpad + (size_t)p * VEC) >> 2;
+                        reinterpret_cast<uint2*>(planes)[o] = make_uint2((a >> 16) | (b & 0xFFFF0000u), (c >> 16) | (d & 0xFFFF0000u));
+                        reinterpret_cast<uint2*>(planes + (size_t)K * Dpad)[o] = make_uint2((a & 0xFFFFu) | (b << 16), (c & 0xFFFFu) | (d << 16));
+                    }
+                }
             }
         }
     }
@@ -720,9 +731,9 @@ __device__ __forceinline__ void sketch_rows(int K, int D, int Dpad, uint64_t see
 
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_sketch_rng(int K, int D, int Dpad, uint64_t seed, uint32_t iter, T* __restrict__ R,
-                                                      double* __restrict__ colsq_part) {
+                                                      double* __restrict__ colsq_part, unsigned short* __restrict__ planes = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    sketch_rows<T, WAVES_PER_BLOCK>(K, D, Dpad, seed, iter, R, colsq_part, blockIdx.x, gridDim.x, reinterpret_cast<double*>(smem_raw));
+    sketch_rows<T, WAVES_PER_BLOCK>(K, D, Dpad, seed, iter, R, colsq_part, blockIdx.x, gridDim.x, reinterpret_cast<double*>(smem_raw), planes);
 }
 
 // fragment image of the matrix-core SpMM rebuilt from the CSR values (after a snapshot restore)

@@ -1,31 +1,35 @@
 // The CSR SpMM of exp(L/2)R on the matrix cores (fp32 handles, locality-blocked patterns).
 //
-// A row block of the blocking (blocking.h) is <= 32 matrix rows whose nonzeros all fall into <= 416 "union" columns, and the
-// blocks of a geometric interference graph are 40-50 % dense in that union.  The block product
+// A row block of the blocking (blocking.h) is <= 32 * MT matrix rows whose nonzeros all fall into <= 416 "union" columns, and
+// the blocks of a geometric interference graph are 40-50 % dense in that union.  The block product
 //     Out[rows, :] = A[rows, union] * U[union, :]
-// is therefore run as a dense 32 x (16 ksteps) x D product on v_mfma_f32_32x32x16_bf16, with both operands split into two
+// is therefore run as a dense (32 MT) x (16 ksteps) x D product on v_mfma_f32_32x32x16_bf16, with both operands split into two
 // bf16 halves (x = hi + lo, 16 significant bits) and the three leading partial products accumulated in fp32:
-//     A U ~= Ahi Uhi + Ahi Ulo + Alo Uhi          relative error <= ~2^-16 of sum |a||u|.
+//     A U ~= Ahi Uhi + Ahi Ulo + Alo Uhi          ||error||_F <= 3 * 2^-17 || |A| ||_2 ||U||_F.
 // The product enters exp(A)b multiplied by the step's norm (rho ~ 3e-3 at the benchmark), so the result keeps the fp32 path's
-// accuracy as long as 2^-15 * max_i sum_j |a_ij| stays below the tolerance; k_plan checks exactly that (ExpmPlan::mfma_ok) and the
-// host falls back to the fp32 LDS kernel (k_spmm_blk2) otherwise.  What this buys: the fp32 kernel spends its time issuing
+// accuracy as long as 2.3e-5 * max_i sum_j |a_ij| stays below the tolerance; k_plan checks exactly that (ExpmPlan::mfma_ok) and
+// the host falls back to the fp32 LDS kernel (k_spmm_blk2) otherwise.  What this buys: the fp32 kernel spends its time issuing
 // one v_pk_fma + one ds_read per nonzero and 16 bytes (VALU 55 % busy, LDS 45 %); here a k-step of 16 union rows costs a wave
 // 4 transposed LDS reads and 3 MFMAs per 32 output columns whatever the fill, and what remains is the gather of the union's
 // rows into LDS (the CU's L2 rate).
 //
 // Operands.
 //   A: k_loss writes every stored entry of L as one 32-bit word (bf16 hi << 16 | bf16 lo) into a dense image of the block in
-//      MFMA fragment order, [block k-step][lane][8]: lane l = (row r = l & 31, half h = l >> 5) holds A[r][16 s + 8 h + j],
-//      j = 0..7 -- the A operand map of v_mfma_f32_32x32x16_bf16 -- so a wave fetches a k-step's fragment with two fully
-//      coalesced 16-byte loads per lane and separates the halves with 8 v_perm_b32.  Holes stay zero (the pattern is fixed).
+//      MFMA fragment order, [block k-step][row tile][half][lane][4]: lane l = (row r = l & 31, k half h = l >> 5) holds
+//      A[r][16 s + 8 h + j], j = 0..7 -- the A operand map of v_mfma_f32_32x32x16_bf16 -- words j = 0..3 in the first 1-KiB half,
+//      j = 4..7 in the second.  Holes stay zero (the pattern is fixed).
 //   U: the producer of a Krylov block also writes its bf16 hi / lo planes ([K][Dpad] each, the same bytes as the fp32 block).
-//      A k-step's 16 union rows of both planes are staged in LDS row-major, exactly as gathered, and read back with
-//      ds_read_b64_tr_b16: the hardware transpose delivers, per lane, 4 consecutive k of one column -- the B operand map.
-//      A row's 64-byte groups are rotated by (row & 3) where the pitch would otherwise put the four rows of a transposed read on
-//      the same banks.
-// One workgroup = (row block, group of 4 * NT column tiles of 32); wave w owns NT column tiles (48 accumulator registers at
-// NT = 3); two LDS buffers, one barrier per k-step; the fused Lanczos epilogue (o = a A u - shift u, u.o and o.o column slabs)
-// works straight on the accumulator layout: a lane holds 16 rows of one column, the other 16 sit in lane + 32.
+// Pipeline.  One workgroup = (row block, group of NW * NT column tiles of 32 columns); wave w owns NT column tiles x MT row
+// tiles.  A k-step's chunk -- the 16 union rows of both planes for the group's columns, row-major exactly as gathered, plus the
+// A fragments of the step -- goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: per-lane source address, lane-linear 1-KiB
+// destination, no registers), three chunks deep: while step s is multiplied, the pieces of steps s+1 and s+2 are in flight
+// (48-56 KiB per workgroup, two or three workgroups per CU).  Per step: a counted s_waitcnt vmcnt for the wave's own pieces of
+// chunk s, ONE s_barrier, the DMA issue for chunk s+2 into the buffer everyone left at that barrier, then
+// ds_read_b64_tr_b16 x 4 (the hardware transpose delivers, per lane, 4 consecutive k of one column: the B operand map)
+// and 3 MFMAs per (row tile, column tile).  A staged row's 64-byte groups are rotated by (row & 3) where the pitch would
+// otherwise put the four rows of a transposed read on the same banks.
+// The fused Lanczos epilogue (o = a A u - shift u, u.o and o.o column slabs) works straight on the accumulator layout:
+// a lane holds 16 rows of one column, the other 16 sit in lane + 32.
 #pragma once
 #include "kernels_expm.h"
 
@@ -55,21 +59,61 @@ __global__ __launch_bounds__(BLOCK) void k_split_planes(size_t n4, const float4*
     }
 }
 
-constexpr int MF_THREADS = 256;
-constexpr int MF_WAVES = MF_THREADS / WAVE;
 constexpr int MF_KROWS = 16;  // union rows per k-step
-struct MfmaDev {
-    const int* kbase;        // [nb+1] k-steps before each block
+constexpr int MF_UNION_ROWS = 640;  // == MF_UNION (blocking.h)
+constexpr int MF_KPAD = 2;    // a block's k-steps are padded to a multiple of this in the fragment image (zero fragments)
+struct MfmaDev {             // the matrix-core kernel's own row blocks (blocking.h, build_mfma_blocking)
+    int nb;
+    const int* desc;         // [nb][8] {first position, rows, 0, 0, 0, union size, 0, 0}
+    const int* un_fixed;     // [nb][MF_UNION_ROWS] union column ids, padded with the first
+    const int* order;        // position -> matrix row
+    const int* kbase;        // [nb+1] (padded) k-steps before each block
     const unsigned* afrag;   // fragment-ordered image of the matrix, hi << 16 | lo
 };
-template <int NT> constexpr int mf_lds_bytes() { return BLK_UNION_ROWS * 4 + 128 + 2 * (2 * MF_KROWS * MF_WAVES * NT * 64); }
+// a chunk = KC k-steps: per k-step the B image (2 planes x 16 rows x the group's columns), then the A fragments of all KC steps
+// GT = column tiles per workgroup
+template <int MT, int GT, int KC> constexpr int mf_chunk_bytes() { return KC * (2048 * GT + 2048 * MT); }
+// NB = chunks resident in LDS (one being multiplied, NB - 1 in flight)
+template <int MT, int GT, int KC, int NB> constexpr int mf_lds_bytes() { return MF_UNION_ROWS * 4 + 64 * 4 + NB * mf_chunk_bytes<MT, GT, KC>(); }
 
-template <int MODE, int NT>
-__global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
-void k_spmm_mfma(BlkDev B, MfmaDev M, int Dpad, size_t plane_bytes, const char* __restrict__ Upl, const float* __restrict__ U,
+// s_waitcnt vmcnt(n) for a wave-uniform n known only at run time (the instruction takes an immediate)
+__device__ __forceinline__ void mf_wait_vmcnt(int n) {
+    switch (n) {
+#define MMW_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+        MMW_W(0) MMW_W(1) MMW_W(2) MMW_W(3) MMW_W(4) MMW_W(5) MMW_W(6) MMW_W(7) MMW_W(8) MMW_W(9) MMW_W(10) MMW_W(11) MMW_W(12)
+        MMW_W(13) MMW_W(14) MMW_W(15) MMW_W(16) MMW_W(17) MMW_W(18) MMW_W(19) MMW_W(20) MMW_W(21) MMW_W(22) MMW_W(23) MMW_W(24)
+        MMW_W(25) MMW_W(26) MMW_W(27) MMW_W(28) MMW_W(29) MMW_W(30) MMW_W(31) MMW_W(32) MMW_W(33) MMW_W(34) MMW_W(35) MMW_W(36)
+        MMW_W(37) MMW_W(38) MMW_W(39) MMW_W(40) MMW_W(41) MMW_W(42) MMW_W(43) MMW_W(44) MMW_W(45) MMW_W(46) MMW_W(47) MMW_W(48)
+#undef MMW_W
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// n / d for the small non-negative integers of the piece decode (n < 4096, d <= 1024): exact, no integer division
+__device__ __forceinline__ int mf_div(int n, int d, float rd) { (void)d; return (int)(((float)n + 0.5f) * rd); }
+// One LDS-DMA piece: 64 lanes x 16 bytes from per-lane global addresses to the 1 KiB of LDS at byte address `lds` (wave-uniform).
+// Written as inline assembly on purpose: the compiler orders every later LDS read behind a global_load_lds it knows about with
+// s_waitcnt vmcnt(0) (it cannot tell the buffers apart), which drains the chunks that are supposed to stay in flight across the
+// products of this step.  The waits for these pieces are the counted ones in the main loop.
+__device__ __forceinline__ void mf_dma16(const char* src, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds) : "memory", "m0");
+}
+
+// MT row tiles per block, NT column tiles per wave, NW waves of which MS groups split the row tiles among them
+// (NW / MS waves side by side along the columns), KC k-steps per chunk, NB chunks resident
+template <int MODE, int MT, int NT, int NW, int MS, int KC, int NB>
+__global__ __launch_bounds__(NW * 64)
+void k_spmm_mfma(MfmaDev M, int Dpad, size_t plane_bytes, const char* __restrict__ Upl, const float* __restrict__ U,
                  float* __restrict__ Out, double ascale_d, double shift_d, double* __restrict__ partial, double* __restrict__ partial_o2,
-                 const ExpmPlan* __restrict__ plan, int step, int* __restrict__ viol) {
+                 const ExpmPlan* __restrict__ plan, int step, int* __restrict__ viol, unsigned long long* __restrict__ stamps) {
     static_assert(MODE == SPMM_PLAIN || MODE == SPMM_LANCZOS, "the matrix-core SpMM has the plain and the Lanczos epilogue");
+    static_assert(MF_KPAD % KC == 0, "the fragment image pads a block's k-steps to whole chunks");
+    // diagnostic runs only (stamps != nullptr): shader-clock sums per wave {prologue, wait + barrier, DMA issue, products, epilogue, steps}
+    unsigned long long tk0 = 0, tk1 = 0, acc_wait = 0, acc_issue = 0, acc_comp = 0, t_pro = 0;
+    if (stamps) tk0 = __builtin_amdgcn_s_memtime();
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef const __attribute__((address_space(1))) void* glb_vp;
+    constexpr int THREADS = NW * 64;
     bool shifted = false;
     if (plan) {
         if (MODE == SPMM_LANCZOS) {
@@ -81,113 +125,150 @@ void k_spmm_mfma(BlkDev B, MfmaDev M, int Dpad, size_t plane_bytes, const char* 
         if (!plan->mfma_ok && viol && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *viol = 1;
     }
     const float ascale = (float)ascale_d, shift = (float)shift_d;
-    constexpr int GT = MF_WAVES * NT;  // column tiles (32 columns, 64 bytes per plane row) per workgroup
+    static_assert(NW % MS == 0 && MT % MS == 0, "row tiles and waves split evenly");
+    constexpr int NWN = NW / MS;   // waves side by side along the columns
+    constexpr int MTW = MT / MS;   // row tiles per wave
+    constexpr int GT = NWN * NT;   // column tiles (32 columns, 64 bytes per plane row) per workgroup
+    constexpr int CHUNK = mf_chunk_bytes<MT, GT, KC>();
+    constexpr int B1 = 2048 * GT;      // B image of one k-step (at the group's full width)
+    constexpr int A_OFF = KC * B1;     // the A fragments sit behind the B images of the chunk
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    int* un_l = reinterpret_cast<int*>(smem_raw);                   // [BLK_UNION_ROWS] union column ids
-    int* orow_l = reinterpret_cast<int*>(smem_raw + BLK_UNION_ROWS * 4);  // [32] output rows
-    char* bufs = smem_raw + BLK_UNION_ROWS * 4 + 128;
-    constexpr int BUF_BYTES = 2 * MF_KROWS * GT * 64;
+    int* un_l = reinterpret_cast<int*>(smem_raw);                         // [MF_UNION_ROWS] union column ids
+    int* orow_l = reinterpret_cast<int*>(smem_raw + MF_UNION_ROWS * 4);  // [64] output rows
+    char* bufs = smem_raw + MF_UNION_ROWS * 4 + 64 * 4;
+    const unsigned bufs_l = (unsigned)(size_t)(lds_vp)bufs;  // LDS byte address of the chunk buffers
 
-    const int per = (B.nb + 7) >> 3;
+    const int per = (M.nb + 7) >> 3;
     const int rb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);  // consecutive row blocks share an XCD's L2
-    if (rb >= B.nb) return;
+    if (rb >= M.nb) return;
     const int col0 = blockIdx.y * (GT * 32);
     const int ng = min(GT, (Dpad - col0) >> 5);  // column tiles of this group (Dpad is a multiple of 32)
     const int spr = ng * 4;                      // 16-byte slots per plane row
-    const int* dsc = B.desc + (size_t)rb * 8;
-    const int q0 = dsc[0], nrows = dsc[1], nun = dsc[5];
-    const int KS = (nun + MF_KROWS - 1) / MF_KROWS;
+    const int* dsc = M.desc + (size_t)rb * 8;
+    const int q0 = dsc[0], nrows = dsc[1];
     const int kb = M.kbase[rb];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int KS = M.kbase[rb + 1] - kb;  // padded to a multiple of MF_KPAD: the padding fragments are zero
+    const int NC = KS / KC;               // chunks
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wv / NWN, wn = wv - wm * NWN;  // this wave's row-tile group and column position
 
-    for (int i = threadIdx.x; i < KS * MF_KROWS; i += MF_THREADS) un_l[i] = B.un_fixed[(size_t)rb * BLK_UNION_ROWS + i];
-    if ((int)threadIdx.x < 32) orow_l[threadIdx.x] = (int)threadIdx.x < nrows ? B.order[q0 + threadIdx.x] : -1;
+    for (int i = threadIdx.x; i < KS * MF_KROWS; i += THREADS) un_l[i] = M.un_fixed[(size_t)rb * MF_UNION_ROWS + i];
+    if ((int)threadIdx.x < 64) orow_l[threadIdx.x] = (int)threadIdx.x < nrows ? M.order[q0 + threadIdx.x] : -1;
 
     // bank rotation of the 64-byte groups of a staged row (see the header): 4 rows of a transposed read on 4 bank quarters
     const int rmode = (ng & 3) == 0 ? 2 : ((ng & 3) == 2 ? 1 : 0);
     auto rot = [&](int q) { return rmode == 2 ? q : (rmode == 1 ? (q >> 1) : 0); };
 
-    // staging slots of this thread: slot = tid + 256 j -> (plane, row, 16-byte slot of the row), fixed for all k-steps
-    constexpr int NS = 2 * NT;
-    unsigned soff[NS];  // byte offset of the source piece relative to (plane 0, row 0); ~0u: idle
-    int srow[NS];
+    // DMA pieces of this wave: piece i = wv + NW j of a chunk (j < cw).  Per k-step kk of the chunk, pieces [0, 2 ng) are 1-KiB
+    // runs of the B image (64 slots of 16 bytes: slot -> plane, row, 16-byte piece of the row) and pieces [2 ng, 2 ng + 2 MT) the
+    // A fragment halves.  Both kinds share one address form, src = base + un_l[16 KC c + row] * mul + c * step (B: mul = row
+    // pitch, step = 0; A: mul = 0), so the issue loop has no branch but the piece count.
+    constexpr int NJ = (KC * (2 * GT + 2 * MT) + NW - 1) / NW;
+    const int nB1 = 2 * ng, nP1 = nB1 + 2 * MT, nI = KC * nP1;
+    const int cw = wv < nI ? (nI - wv + NW - 1) / NW : 0;  // pieces of this wave per chunk
+    const char* pbase[NJ];
+    unsigned pmul[NJ];
+    int prow[NJ], pdst[NJ];
     const unsigned pitch = (unsigned)Dpad * 2u;
+    const char* afr = reinterpret_cast<const char*>(M.afrag) + (size_t)kb * (2048 * MT);
+    const float rP1 = 1.0f / (float)nP1, rspr = 1.0f / (float)spr;
 #pragma unroll
-    for (int j = 0; j < NS; ++j) {
-        const int slot = threadIdx.x + MF_THREADS * j;
-        soff[j] = ~0u;
-        srow[j] = 0;
-        if (slot < 2 * MF_KROWS * spr) {
-            const int p = slot / (MF_KROWS * spr), rem = slot - p * (MF_KROWS * spr);
-            const int r = rem / spr, t = rem - r * spr;
+    for (int j = 0; j < NJ; ++j) {
+        const int i = wv + NW * j;
+        const int kk = mf_div(i, nP1, rP1), i1 = i - kk * nP1;
+        pbase[j] = Upl;
+        pmul[j] = 0;
+        prow[j] = 0;
+        pdst[j] = 0;
+        if (i < nI && i1 < nB1) {
+            const int slot = i1 * 64 + lane;
+            const int p = slot >= MF_KROWS * spr ? 1 : 0, rem = slot - p * (MF_KROWS * spr);
+            const int r = mf_div(rem, spr, rspr), t = rem - r * spr;
             int G = (t >> 2) - rot(r & 3);
             if (G < 0) G += ng;
-            soff[j] = (unsigned)p * (unsigned)plane_bytes + (unsigned)col0 * 2u + (unsigned)(G * 4 + (t & 3)) * 16u;
-            srow[j] = r;
+            pbase[j] = Upl + ((size_t)p * plane_bytes + (size_t)col0 * 2u + (size_t)(G * 4 + (t & 3)) * 16u);
+            pmul[j] = pitch;
+            prow[j] = kk * MF_KROWS + r;
+            pdst[j] = kk * B1 + i1 * 1024;
+        } else if (i < nI) {
+            pbase[j] = afr + (kk * (2048 * MT) + (i1 - nB1) * 1024 + lane * 16);
+            pdst[j] = A_OFF + kk * (2048 * MT) + (i1 - nB1) * 1024;
         }
+        pdst[j] = __builtin_amdgcn_readfirstlane(pdst[j]);
     }
-    uint4 st[NS];
-    auto issue = [&](int s) {
+    auto issue = [&](int c) {  // chunk c -> buffer c % NB
+        const unsigned dst_l = bufs_l + (unsigned)((c % NB) * CHUNK);
+        const unsigned astep = (unsigned)c * (unsigned)(KC * 2048 * MT);
 #pragma unroll
-        for (int j = 0; j < NS; ++j)
-            if (soff[j] != ~0u) st[j] = *reinterpret_cast<const uint4*>(Upl + ((size_t)(unsigned)un_l[s * MF_KROWS + srow[j]] * pitch + soff[j]));
-    };
-    auto deposit = [&](int b) {
-#pragma unroll
-        for (int j = 0; j < NS; ++j)
-            if (soff[j] != ~0u) *reinterpret_cast<uint4*>(bufs + b * BUF_BYTES + (threadIdx.x + MF_THREADS * j) * 16) = st[j];
+        for (int j = 0; j < NJ; ++j) {
+            if (j < cw) {  // wave-uniform
+                const char* src = pbase[j] + ((size_t)(unsigned)un_l[c * (KC * MF_KROWS) + prow[j]] * pmul[j] + (pmul[j] ? 0u : astep));
+                mf_dma16(src, dst_l + (unsigned)pdst[j]);
+            }
+        }
     };
 
-    // transposed-read addresses of this lane: 16-lane group g (h = g >> 1: k half, g & 1: column half), lane 4q + p of the group
+    // transposed-read addresses of this lane: 16-lane group g (h = g >> 1: k half, g & 1: column half), lane 4q + p of the group.
+    // Column tiles past the group's last (a partial last group) read tile 0 again and are dropped in the epilogue: no branch
+    // between a step's reads and products.
     const int g16 = lane >> 4, l16 = lane & 15, tq = l16 >> 2, tp = l16 & 3;
     unsigned rbase[NT];
     bool tile_on[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-        const int G = wv * NT + i;
+        const int G = wn * NT + i;
         tile_on[i] = G < ng;
-        int Gp = G + rot(tq);
+        int Gp = (tile_on[i] ? G : 0) + rot(tq);
         if (Gp >= ng) Gp -= ng;
         rbase[i] = (unsigned)((8 * (g16 >> 1) + tq) * spr * 16 + Gp * 64 + (g16 & 1) * 32 + tp * 8);
     }
     const unsigned row4 = (unsigned)(4 * spr * 16), plane_l = (unsigned)(MF_KROWS * spr * 16);
 
-    mf_f16 acc[NT];
+    mf_f16 acc[MTW][NT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+    for (int m = 0; m < MTW; ++m)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[m][i][v] = 0.f;
 
     __syncthreads();  // un_l
-    issue(0);
-    const uint4* ap = reinterpret_cast<const uint4*>(M.afrag) + ((size_t)kb * 64 + lane) * 2;
-    uint4 a0 = ap[0], a1 = ap[1];
-    deposit(0);
-    if (KS > 1) issue(1);
-    __syncthreads();
-    for (int s = 0; s < KS; ++s) {
-        const char* bb = bufs + (s & 1) * BUF_BYTES;
-        // the two halves of the A fragment: word = hi << 16 | lo per k
-        mf_s8 ahi, alo;
-        {
-            const unsigned w[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-            unsigned h[4], l[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                h[i] = __builtin_amdgcn_perm(w[2 * i + 1], w[2 * i], 0x07060302u);
-                l[i] = __builtin_amdgcn_perm(w[2 * i + 1], w[2 * i], 0x05040100u);
+    for (int c = 0; c < NB - 1; ++c)
+        if (c < NC) issue(c);
+    if (stamps) { tk1 = __builtin_amdgcn_s_memtime(); t_pro = tk1 - tk0; }
+    for (int c = 0; c < NC; ++c) {
+        // this wave's pieces of chunk c have landed when at most the pieces of the younger chunks are outstanding
+        const int younger = min(NC - 1 - c, NB - 2);
+        mf_wait_vmcnt(cw * younger);
+        __builtin_amdgcn_s_barrier();  // everyone's pieces of chunk c are in LDS, and everyone has left the buffer of chunk c - 1
+        if (stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_wait += t - tk1; tk1 = t; }
+        if (c + NB - 1 < NC) issue(c + NB - 1);
+        if (stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_issue += t - tk1; tk1 = t; }
+        const char* cb = bufs + (c % NB) * CHUNK;
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+            const char* bb = cb + kk * B1;
+            mf_s8 ahi[MTW], alo[MTW];
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {  // the two halves of the A fragment: word = hi << 16 | lo per k
+                const char* af = cb + A_OFF + (kk * MT + wm * MTW + m) * 2048 + lane * 16;
+                const uint4 a0 = *reinterpret_cast<const uint4*>(af);
+                const uint4 a1 = *reinterpret_cast<const uint4*>(af + 1024);
+                const unsigned w[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                unsigned h[4], l[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    h[i] = __builtin_amdgcn_perm(w[2 * i + 1], w[2 * i], 0x07060302u);
+                    l[i] = __builtin_amdgcn_perm(w[2 * i + 1], w[2 * i], 0x05040100u);
+                }
+                const uint4 hv = make_uint4(h[0], h[1], h[2], h[3]), lv = make_uint4(l[0], l[1], l[2], l[3]);
+                ahi[m] = __builtin_bit_cast(mf_s8, hv);
+                alo[m] = __builtin_bit_cast(mf_s8, lv);
             }
-            const uint4 hv = make_uint4(h[0], h[1], h[2], h[3]), lv = make_uint4(l[0], l[1], l[2], l[3]);
-            ahi = __builtin_bit_cast(mf_s8, hv);
-            alo = __builtin_bit_cast(mf_s8, lv);
-        }
-        if (s + 1 < KS) {  // next fragment flies during the products
-            a0 = ap[(size_t)(s + 1) * 128];
-            a1 = ap[(size_t)(s + 1) * 128 + 1];
-        }
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            if (tile_on[i]) {  // wave-uniform
+            for (int i = 0; i < NT; ++i) {
                 typedef __attribute__((address_space(3))) mf_s4* lp;
                 const char* p0 = bb + rbase[i];
                 const mf_s4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p0));
@@ -196,41 +277,49 @@ void k_spmm_mfma(BlkDev B, MfmaDev M, int Dpad, size_t plane_bytes, const char* 
                 const mf_s4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p0 + plane_l + row4));
                 const mf_s8 bhi = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
                 const mf_s8 blo = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mf_bf8, alo), __builtin_bit_cast(mf_bf8, bhi), acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mf_bf8, ahi), __builtin_bit_cast(mf_bf8, blo), acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mf_bf8, ahi), __builtin_bit_cast(mf_bf8, bhi), acc[i], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) {
+                    acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mf_bf8, alo[m]), __builtin_bit_cast(mf_bf8, bhi), acc[m][i], 0, 0, 0);
+                    acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mf_bf8, ahi[m]), __builtin_bit_cast(mf_bf8, blo), acc[m][i], 0, 0, 0);
+                    acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mf_bf8, ahi[m]), __builtin_bit_cast(mf_bf8, bhi), acc[m][i], 0, 0, 0);
+                }
             }
         }
-        if (s + 1 < KS) {
-            deposit((s + 1) & 1);  // everyone left that buffer at the barrier that ended step s - 1
-            if (s + 2 < KS) issue(s + 2);
-        }
-        __syncthreads();
+        if (stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_comp += t - tk1; tk1 = t; }
     }
 
-    // ---- epilogue on the accumulator layout: lane = column (lane & 31), register v = row (v & 3) + 8 (v >> 2) + 4 (lane >> 5)
+    // ---- epilogue on the accumulator layout: lane = column (lane & 31), register v = row (v & 3) + 8 (v >> 2) + 4 (lane >> 5).
+    // Rows past the block's last are computed on row 0's address and dropped at the store: no branch around a load, so a tile's
+    // 16 loads of u are in flight together.
     const int h2 = lane >> 5, cl = lane & 31;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         if (!tile_on[i]) continue;
-        const int col = col0 + (wv * NT + i) * 32 + cl;
+        const int col = col0 + (wn * NT + i) * 32 + cl;
         float dot = 0.f, dot2 = 0.f;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int rl = (v & 3) + 8 * (v >> 2) + 4 * h2;
-            const int row = orow_l[rl];
-            if (row >= 0) {
-                const size_t off = (size_t)row * Dpad + col;
+        for (int m = 0; m < MTW; ++m) {
+            int rows[16];
+            float u[16];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) rows[v] = orow_l[32 * (wm * MTW + m) + (v & 3) + 8 * (v >> 2) + 4 * h2];
+            if (MODE == SPMM_LANCZOS) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) u[v] = U[(size_t)max(rows[v], 0) * Dpad + col];
+            }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
                 float o;
                 if (MODE == SPMM_LANCZOS) {
-                    const float u = U[off];
-                    o = ascale * acc[i][v] - shift * u;  // shift is 0 unless the recurrence runs on A - mu I
-                    dot += u * o;
-                    dot2 += o * o;
+                    o = ascale * acc[m][i][v] - shift * u[v];  // shift is 0 unless the recurrence runs on A - mu I
+                    if (rows[v] >= 0) {
+                        dot += u[v] * o;
+                        dot2 += o * o;
+                    }
                 } else {
-                    o = ascale * acc[i][v];
+                    o = ascale * acc[m][i][v];
                 }
-                Out[off] = o;
+                if (rows[v] >= 0) Out[(size_t)rows[v] * Dpad + col] = o;
             }
         }
         if (MODE == SPMM_LANCZOS) {
@@ -239,11 +328,36 @@ void k_spmm_mfma(BlkDev B, MfmaDev M, int Dpad, size_t plane_bytes, const char* 
             const float d1 = a + b;
             rows32(dot2, a, b);
             const float d2 = a + b;
-            if (h2 == 0) {
-                partial[(size_t)rb * Dpad + col] = (double)d1;
-                if (shifted) partial_o2[(size_t)rb * Dpad + col] = (double)d2;
+            if (MS == 1) {
+                if (h2 == 0) {
+                    partial[(size_t)rb * Dpad + col] = (double)d1;
+                    if (shifted) partial_o2[(size_t)rb * Dpad + col] = (double)d2;
+                }
+            } else if (h2 == 0) {  // the row-tile groups meet in LDS below (the chunk buffers are free now)
+                float* red = reinterpret_cast<float*>(bufs);
+                red[((wm * GT + wn * NT + i) * 32 + cl) * 2] = d1;
+                red[((wm * GT + wn * NT + i) * 32 + cl) * 2 + 1] = d2;
             }
         }
+    }
+    if (MODE == SPMM_LANCZOS && MS > 1) {
+        __syncthreads();  // every wave is past its last chunk: its reads of the buffers are done
+        const float* red = reinterpret_cast<const float*>(bufs);
+        for (int t = threadIdx.x; t < ng * 32; t += THREADS) {
+            float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+            for (int g = 0; g < MS; ++g) {
+                d1 += red[((g * GT) * 32 + t) * 2];
+                d2 += red[((g * GT) * 32 + t) * 2 + 1];
+            }
+            partial[(size_t)rb * Dpad + col0 + t] = (double)d1;
+            if (shifted) partial_o2[(size_t)rb * Dpad + col0 + t] = (double)d2;
+        }
+    }
+    if (stamps && lane == 0) {
+        const unsigned long long te = __builtin_amdgcn_s_memtime();
+        unsigned long long* o = stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wv) * 8;
+        o[0] = t_pro; o[1] = acc_wait; o[2] = acc_issue; o[3] = acc_comp; o[4] = te - tk0; o[5] = (unsigned long long)NC; o[6] = tk0; o[7] = te - tk1;
     }
 }
 

@@ -36,12 +36,7 @@ struct mmw_solver {
 
 namespace {
 
-// budgets of a row block; fp32 handles cap the rows at 32 so that the matrix-core SpMM (kernels_mfma.h) can run on the blocks
-template <typename T> BlockingLimits blocking_limits() {
-    BlockingLimits lim{blk_max_entries<T>(), (int)sizeof(BlkMeta<T>)};
-    if (sizeof(T) == 4 && !getenv("MMW_NO_MFMA")) lim.max_rows = 32;
-    return lim;
-}
+template <typename T> BlockingLimits blocking_limits() { return BlockingLimits{blk_max_entries<T>(), (int)sizeof(BlkMeta<T>)}; }
 
 template <typename T> struct Solver final : mmw_solver {
     int device = 0;
@@ -73,7 +68,7 @@ template <typename T> struct Solver final : mmw_solver {
     uint64_t sketch_done_seed = 0;
     int sketch_done_slabs = 0;
     DevBuf<T> lval_blk;
-    DevBuf<int> b_kbase, b_fpos;     // matrix-core SpMM: k-steps before each block, CSR entry -> fragment image position
+    DevBuf<int> b_kbase, b_fpos, b_mdesc, b_munfixed, b_morder;  // matrix-core SpMM: its row blocks, CSR entry -> fragment image position
     DevBuf<unsigned> afrag;          // the matrix as bf16 hi << 16 | lo words in MFMA fragment order
     size_t afrag_n = 0;
     int blocking_mode = 1;  // 1: use when profitable, 0: never
@@ -129,6 +124,10 @@ template <typename T> struct Solver final : mmw_solver {
                         (tnow() - t0) * 1e3, (int)HB.usable, (int)HB.fits_half_tile, HB.nb(), (double)K / std::max(1, HB.nb()),
                         (double)HB.un_cols.size() / std::max(1, HB.nb()), HB.reuse, (long long)HB.nent, (long long)H.nnzL(),
                         100.0 * ((double)HB.nent / (double)H.nnzL() - 1.0), HB.sd2_rounds);
+                const double t1 = tnow();
+                build_mfma_blocking(HB, K, H.l_indptr, H.l_indices, getenv("MMW_MF_ROWS") ? atoi(getenv("MMW_MF_ROWS")) : 64);
+                fprintf(stderr, "[mmw] matrix-core blocking %.1f ms: ok %d blocks %d rows/block %.1f reuse %.2f row tiles %d k-steps %d\n", (tnow() - t1) * 1e3,
+                        (int)HB.fits_mfma, HB.nbm(), (double)K / std::max(1, HB.nbm()), HB.m_reuse, HB.mfma_mt, HB.kbase.empty() ? 0 : HB.kbase.back());
             }
             if (getenv("MMW_CHECK_BLOCKING")) {  // CPU tests: build the blocking and check its invariants
                 const BlockingLimits lim = blocking_limits<T>();
@@ -136,6 +135,11 @@ template <typename T> struct Solver final : mmw_solver {
                 if (!HB.order.empty() && !HB.blk_rowptr.empty() && HB.blk_rowptr.back() == K) {
                     const std::string berr = verify_blocking(HB, K, H.l_indptr, H.l_indices, lim);
                     if (!berr.empty()) return fail(MMW_ERR_STATE, "blocking invariant violated: " + berr);
+                    for (int mrows : {64, 32, 7}) {
+                        build_mfma_blocking(HB, K, H.l_indptr, H.l_indices, mrows);
+                        const std::string merr = verify_mfma_blocking(HB, K, H.l_indptr, H.l_indices);
+                        if (!merr.empty()) return fail(MMW_ERR_STATE, "blocking invariant violated: " + merr);
+                    }
                 }
             }
             return MMW_OK;
@@ -247,15 +251,34 @@ template <typename T> struct Solver final : mmw_solver {
                                         std::max(HB.un8_max * B2_ROW_BYTES, 65536)));
             sddmm_blk2 = true;
         }
-        if (sizeof(T) == 4 && HB.fits_mfma && !getenv("MMW_NO_MFMA") && (double)K * eng.lay.Dpad * 4.0 < 4.0e9) {
+        if (sizeof(T) == 4 && !getenv("MMW_NO_MFMA") && (double)K * eng.lay.Dpad * 4.0 < 4.0e9) {
+            const int mrows = getenv("MMW_MF_ROWS") ? atoi(getenv("MMW_MF_ROWS")) : 64;
+            build_mfma_blocking(HB, K, H.l_indptr, H.l_indices, std::min(64, std::max(1, mrows)));
+            if (getenv("MMW_VERBOSE"))
+                fprintf(stderr, "[mmw] matrix-core blocking: ok %d blocks %d rows/block %.1f reuse %.2f row tiles %d k-steps %d\n", (int)HB.fits_mfma, HB.nbm(),
+                        (double)K / std::max(1, HB.nbm()), HB.m_reuse, HB.mfma_mt, HB.kbase.empty() ? 0 : HB.kbase.back());
+        }
+        if (sizeof(T) == 4 && HB.fits_mfma) {
             MMW_TRY(b_kbase.upload(HB.kbase, st));
             MMW_TRY(b_fpos.upload(HB.fpos, st));
-            afrag_n = (size_t)HB.kbase[HB.nb()] * 512;
+            MMW_TRY(b_mdesc.upload(HB.m_desc, st));
+            MMW_TRY(b_munfixed.upload(HB.m_unfixed, st));
+            MMW_TRY(b_morder.upload(HB.m_order, st));
+            afrag_n = (size_t)HB.kbase[HB.nbm()] * HB.mfma_mt * 512;
             MMW_TRY(afrag.alloc(afrag_n));
             MMW_HIP(hipMemsetAsync(afrag.p, 0, afrag_n * sizeof(unsigned), st));
             eng.use_mfma = true;
+            eng.mf.nb = HB.nbm();
+            eng.mf.desc = b_mdesc.p;
+            eng.mf.un_fixed = b_munfixed.p;
+            eng.mf.order = b_morder.p;
             eng.mf.kbase = b_kbase.p;
             eng.mf.afrag = afrag.p;
+            eng.mf_mt = HB.mfma_mt;
+            if ((size_t)HB.nbm() > (size_t)MAX_PART && HB.nbm() > HB.nb()) {
+                MMW_TRY(eng.partial.alloc((size_t)HB.nbm() * eng.lay.Dpad));
+                MMW_TRY(eng.partial_o2.alloc((size_t)HB.nbm() * eng.lay.Dpad));
+            }
         }
         MMW_HIP(hipStreamSynchronize(st));
         extras.fac.set_blocking(blkdev(), b_bepos.p, HB.nent);
@@ -396,7 +419,29 @@ template <typename T> struct Solver final : mmw_solver {
         for (int r = 0; r < reps && rc == MMW_OK; ++r) rc = one();
         MMW_HIP(hipEventRecord(e1, st));
         MMW_HIP(hipStreamSynchronize(st));
-        if (want_stamps) {
+        if (want_stamps && blocked == 2) {  // matrix-core kernel: per-wave phase clocks
+            g_mf_stamps = stamps.p;
+            rc = one();
+            g_mf_stamps = nullptr;
+            std::vector<unsigned long long> h((size_t)16 * 8192);
+            MMW_HIP(hipMemcpyAsync(h.data(), stamps.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            MMW_HIP(hipStreamSynchronize(st));
+            double sum[5] = {0}, steps = 0, life_max = 0, epi = 0;
+            int n = 0;
+            for (size_t w = 0; w < h.size() / 8; ++w) {
+                const unsigned long long* q = &h[w * 8];
+                if (!q[4]) continue;
+                ++n;
+                for (int k = 0; k < 5; ++k) sum[k] += (double)q[k];
+                steps += (double)q[5];
+                life_max = std::max(life_max, (double)q[4]);
+                epi += (double)q[7];
+            }
+            if (n)
+                fprintf(stderr, "[mf stamps] %d waves, %.1f k-steps each; shader clocks per wave: prologue %.0f, wait+barrier %.0f (%.0f/step), issue %.0f (%.0f/step), "
+                                "products %.0f (%.0f/step), epilogue %.0f, lifetime %.0f (max %.0f)\n", n, steps / n, sum[0] / n, sum[1] / n, sum[1] / steps,
+                        sum[2] / n, sum[2] / steps, sum[3] / n, sum[3] / steps, epi / n, sum[4] / n, life_max);
+        } else if (want_stamps) {
             g_blk_stamps = stamps.p;
             rc = one();
             g_blk_stamps = nullptr;
@@ -597,8 +642,10 @@ template <typename T> struct Solver final : mmw_solver {
     int launch_sketch(hipStream_t s, uint64_t seed, uint32_t it) {
         const bool lz = eng.method == MMW_EXPM_LANCZOS;
         const int Dpad = eng.lay.Dpad;
+        unsigned short* pl = eng.start_planes();
         hipLaunchKernelGGL((k_sketch_rng<T>), dim3(sketch_slabs()), dim3(BLOCK), lz ? (size_t)WAVES_PER_BLOCK * Dpad * sizeof(double) : 0, s, K, D, Dpad,
-                           seed, it, eng.start_block(), lz ? eng.partial_sq.p : (double*)nullptr);
+                           seed, it, eng.start_block(), lz ? eng.partial_sq.p : (double*)nullptr, pl);
+        eng.planes_ready[0] = pl != nullptr;
         MMW_HIP(hipGetLastError());
         return MMW_OK;
     }
@@ -637,6 +684,8 @@ template <typename T> struct Solver final : mmw_solver {
                 skl.nblocks = sketch_slabs(); skl.K = K; skl.D = D; skl.seed = seed; skl.iter = (uint32_t)iter;
                 skl.R = eng.start_block();
                 skl.colsq_part = lz_m ? eng.partial_sq.p : nullptr;
+                skl.planes = eng.start_planes();
+                eng.planes_ready[0] = skl.planes != nullptr;
                 sketch_done_for = (int64_t)iter; sketch_done_seed = seed; sketch_done_slabs = skl.nblocks;
             }
             hipLaunchKernelGGL((k_loss<T>), dim3(gl + skl.nblocks), dim3(BLOCK), skl.nblocks && lz_m ? (size_t)WAVES_PER_BLOCK * Dpad * sizeof(double) : 0,
@@ -651,6 +700,7 @@ template <typename T> struct Solver final : mmw_solver {
             if (randv) {
                 MMW_HIP(hipMemcpyAsync(stage64.p, randv + (size_t)it * K * D, (size_t)K * D * sizeof(double), hipMemcpyHostToDevice, st));
                 hipLaunchKernelGGL((k_import_block<T>), dim3(grid_elems(eng.bs)), dim3(BLOCK), 0, st, K, D, Dpad, stage64.p, eng.start_block());
+                eng.planes_ready[0] = false;  // an uploaded sketch is split by a pass of its own
                 last_was_rng = false;
             } else {
                 const bool have = sketch_done_for == (int64_t)iter && sketch_done_seed == seed;  // drawn by the previous SDDMM launch
@@ -691,6 +741,8 @@ template <typename T> struct Solver final : mmw_solver {
                     sk.K = K; sk.D = D; sk.seed = seed; sk.iter = (uint32_t)(iter + 1);
                     sk.R = eng.start_block();
                     sk.colsq_part = lzm ? eng.partial_sq.p : nullptr;
+                    sk.planes = eng.start_planes();
+                    eng.planes_ready[0] = sk.planes != nullptr;
                     sketch_done_for = (int64_t)iter + 1;
                     sketch_done_seed = seed;
                     sketch_done_slabs = sk.nblocks * VBW;

@@ -16,7 +16,8 @@ print("create %.3fs" % (time.time() - t0), "K", s.K, "D", s.D, "nnzL", s.nnzL, "
 s.iterate(3, None, 1)
 w = 4 if dt == "f32" else 8
 b = s.nnzL * (w + 4) + (s.K + 1) * 4 + 2 * s.K * s.D * w
-for blocked in (0, 1, 2):  # generic gather, LDS-staged fp32, matrix cores
+modes = [int(x) for x in os.environ.get('MMW_BENCH_MODES', '0,1,2').split(',')]
+for blocked in modes:  # 0 generic gather, 1 LDS-staged fp32, 2 matrix cores
     try:
         us = s.bench_spmm(blocked, 30)
         print("blocked=%d  %.1f us  -> %.0f GB/s algorithmic (%.1f%% of 8 TB/s)" % (blocked, us, b / us / 1e3, b / us / 1e3 / 80))
