@@ -276,4 +276,210 @@ __global__ __launch_bounds__(BLOCK) void k_greedy(int K, int Z, int maxdeg, int 
     if (threadIdx.x == 0) rem[b] = unassigned;
 }
 
+
+// ---- the same greedy pass, several users per step ------------------------------------------------------------------------
+// The loop above is sequential in the users because a user's decision reads what earlier users wrote: slot[] of its out- and
+// access-point neighbours, its own row of gain sums and the sums of its neighbours.  Two users a, b touch disjoint state -- and
+// can be decided in the same step with the reference's result -- unless a is an out-neighbour of b or b of a, they share an access
+// point, or they have a common out-neighbour.  The visiting order is by descending ||gX_k||, unrelated to the geometry, so on an
+// interference graph consecutive users rarely interact (~4 % of pairs at the benchmark).  k_greedy_conflicts finds, for every
+// position of the order, the nearest earlier position within the window that it interacts with; k_greedy_b then takes, per step,
+// the longest run of positions free of such pairs (up to GB_WAVES), one wavefront per user: every check, the preference scan and
+// the sum updates of a user are wave-level (no workgroup barrier inside a step), and one full barrier per step publishes the
+// step's slots and sums.  The sums are still formed one add per address and step, in assignment order (sdp_solver.py:94).
+constexpr int GB_WAVES = 8;
+constexpr int GB_NE = 4;   // neighbour chunks (64 each) kept in registers one step ahead; longer lists are re-read in place
+constexpr int GB_NP = 4;   // preference chunks kept in registers one step ahead (Z <= 256); longer rows are re-read in place
+
+__device__ __forceinline__ bool sorted_contains(const int* __restrict__ a, int n, int x) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo < n && a[lo] == x;
+}
+// lag[i] = smallest d in [1, GB_WAVES) such that the users at positions i and i - d interact; 0 if none.  One thread per (i, d).
+__global__ __launch_bounds__(BLOCK) void k_greedy_conflicts(int K, const GreedyHdr* __restrict__ hdr, const int* __restrict__ so_indices,
+                                                            const int* __restrict__ q_indices, int* __restrict__ lag) {
+    const int t = blockIdx.x * BLOCK + threadIdx.x;
+    const int i = t / (GB_WAVES - 1), d = t % (GB_WAVES - 1) + 1;
+    if (i >= K || i - d < 0) return;
+    const GreedyHdr a = hdr[i - d], b = hdr[i];
+    const int* na = so_indices + a.sb;
+    const int* nb = so_indices + b.sb;
+    bool hit = sorted_contains(na, a.deg, b.k) || sorted_contains(nb, b.deg, a.k) || sorted_contains(q_indices + b.qb, b.qdeg, a.k);
+    for (int x = 0, y = 0; !hit && x < a.deg && y < b.deg;) {  // common out-neighbour: merge of the two sorted lists
+        const int u = na[x], v = nb[y];
+        if (u == v) hit = true;
+        else if (u < v) ++x;
+        else ++y;
+    }
+    if (hit) atomicMin(&lag[i], d);
+}
+
+template <bool SLOT_LDS>
+__global__ __launch_bounds__(GB_WAVES * 64) void k_greedy_b(int K, int Z, const GreedyHdr* __restrict__ hdr, const int* __restrict__ lag,
+                                                            const int* __restrict__ pref_all, const int* __restrict__ so_indices,
+                                                            const double* __restrict__ so_data, const double* __restrict__ so_hmax,
+                                                            const int* __restrict__ q_indices, double* __restrict__ gain_all,
+                                                            int* __restrict__ slot_all, int* __restrict__ rem) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    // layout: bad[GB_WAVES][Z] int, lag_l[K] u8 (rounded up to 4), slot_l[K] int (optional)
+    int* bad_all = reinterpret_cast<int*>(smem_raw);
+    unsigned char* lag_l = reinterpret_cast<unsigned char*>(smem_raw + (size_t)GB_WAVES * Z * 4);
+    int* slot_l = reinterpret_cast<int*>(smem_raw + (size_t)GB_WAVES * Z * 4 + (((size_t)K + 3) & ~(size_t)3));
+    __shared__ int unassigned;
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int* pref = pref_all + (size_t)b * K * Z;
+    double* gain = gain_all + (size_t)b * K * Z;  // [K][Z]
+    int* slot_g = slot_all + (size_t)b * K;
+    int* slot = SLOT_LDS ? slot_l : slot_g;
+    int* bad = bad_all + (size_t)wv * Z;
+    for (int i = threadIdx.x; i < K; i += GB_WAVES * 64) {
+        const int l = lag[i];
+        lag_l[i] = (unsigned char)(l >= GB_WAVES ? 0 : l);
+        if (SLOT_LDS) slot_l[i] = -1;
+    }
+    if (threadIdx.x == 0) unassigned = 0;
+
+    // static data of the user this wave may decide in the coming step (position start + wv), requested one step ahead
+    GreedyHdr h;
+    int r_n[GB_NE], r_q = 0, r_p[GB_NP];
+    double r_v[GB_NE], r_h[GB_NE];
+    auto prefetch = [&](int pos) {
+        if (pos >= K) { h.k = -1; h.deg = 0; h.qdeg = 0; return; }
+        h = hdr[pos];
+#pragma unroll
+        for (int i = 0; i < GB_NE; ++i) {
+            const int e = lane + 64 * i;
+            r_n[i] = e < h.deg ? so_indices[h.sb + e] : 0;
+            r_v[i] = e < h.deg ? so_data[h.sb + e] : 0.0;
+            r_h[i] = e < h.deg ? so_hmax[h.sb + e] : 0.0;
+        }
+        r_q = lane < h.qdeg ? q_indices[h.qb + lane] : 0;
+#pragma unroll
+        for (int i = 0; i < GB_NP; ++i) {
+            const int zz = lane + 64 * i;
+            r_p[i] = zz < Z ? pref[(size_t)h.k * Z + zz] : 0;
+        }
+    };
+    prefetch(wv);
+    __syncthreads();
+    int start = 0;
+    while (start < K) {
+        // the longest run of positions from `start` in which no two users interact
+        int ext;
+        {
+            const int t = lane;  // candidate position start + t
+            bool stop = t >= GB_WAVES || start + t >= K;
+            if (!stop && t >= 1) {
+                const int l = lag_l[start + t];
+                stop = l != 0 && l <= t;
+            }
+            const unsigned long long m = __ballot(stop && t >= 1);
+            ext = m ? (int)__builtin_ctzll(m) : GB_WAVES;
+        }
+        const int next = start + ext;
+        // the decision of user `cur` (wave-uniform everything)
+        const GreedyHdr cur = h;
+        int c_n[GB_NE], c_q = r_q, c_p[GB_NP];
+        double c_v[GB_NE], c_h[GB_NE];
+#pragma unroll
+        for (int i = 0; i < GB_NE; ++i) { c_n[i] = r_n[i]; c_v[i] = r_v[i]; c_h[i] = r_h[i]; }
+#pragma unroll
+        for (int i = 0; i < GB_NP; ++i) c_p[i] = r_p[i];
+        const bool active = wv < ext;
+        // the sums on the chain, requested together: own row and, through slot[], each neighbour's sum in its slot
+        double g_self[GB_NP];
+        int zn_e[GB_NE];
+        double g_ne[GB_NE];
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < GB_NP; ++i) {
+                const int z = lane + 64 * i;
+                g_self[i] = z < Z ? __hip_atomic_load(&gain[(size_t)cur.k * Z + z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < GB_NE; ++i) {
+                const int e = lane + 64 * i;
+                zn_e[i] = -1;
+                g_ne[i] = 0.0;
+                if (e < cur.deg) {
+                    zn_e[i] = slot[c_n[i]];
+                    if (zn_e[i] >= 0) g_ne[i] = __hip_atomic_load(&gain[(size_t)c_n[i] * Z + zn_e[i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        prefetch(next + wv);  // after the chain loads: loads return in order, so waiting for those leaves these in flight
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < GB_NP; ++i) {
+                const int z = lane + 64 * i;
+                if (z < Z) bad[z] = g_self[i] > cur.hk ? 1 : 0;
+            }
+            for (int z = lane + 64 * GB_NP; z < Z; z += 64)
+                bad[z] = __hip_atomic_load(&gain[(size_t)cur.k * Z + z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > cur.hk ? 1 : 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < GB_NE; ++i)
+                if (zn_e[i] >= 0 && g_ne[i] + c_v[i] > c_h[i]) bad[zn_e[i]] = 1;
+            for (int e = lane + 64 * GB_NE; e < cur.deg; e += 64) {  // lists longer than the register window
+                const int n = so_indices[cur.sb + e];
+                const int zn = slot[n];
+                if (zn >= 0 && __hip_atomic_load(&gain[(size_t)n * Z + zn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + so_data[cur.sb + e] > so_hmax[cur.sb + e])
+                    bad[zn] = 1;
+            }
+            if (lane < cur.qdeg) {
+                const int zn = slot[c_q];
+                if (zn >= 0) bad[zn] = 1;
+            }
+            for (int e = lane + 64; e < cur.qdeg; e += 64) {
+                const int zn = slot[q_indices[cur.qb + e]];
+                if (zn >= 0) bad[zn] = 1;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // first slot of the preference order that is not ruled out
+            int z_take = -1;
+#pragma unroll
+            for (int i = 0; i < GB_NP; ++i) {
+                if (z_take < 0 && 64 * i < Z) {
+                    const int zz = lane + 64 * i;
+                    const bool ok = zz < Z && !bad[c_p[i]];
+                    const unsigned long long m = __ballot(ok);
+                    if (m) z_take = __shfl(c_p[i], (int)__builtin_ctzll(m));
+                }
+            }
+            for (int z0 = 64 * GB_NP; z_take < 0 && z0 < Z; z0 += 64) {
+                const int zz = lane + z0;
+                const int pz = zz < Z ? pref[(size_t)cur.k * Z + zz] : 0;
+                const bool ok = zz < Z && !bad[pz];
+                const unsigned long long m = __ballot(ok);
+                if (m) z_take = __shfl(pz, (int)__builtin_ctzll(m));
+            }
+            if (z_take >= 0) {
+                // fire-and-forget f64 atomic adds, one per address and step; the full barrier below completes them before the next
+                // step reads the sums
+#pragma unroll
+                for (int i = 0; i < GB_NE; ++i)
+                    if (lane + 64 * i < cur.deg) unsafeAtomicAdd(&gain[(size_t)c_n[i] * Z + z_take], c_v[i]);
+                for (int e = lane + 64 * GB_NE; e < cur.deg; e += 64) unsafeAtomicAdd(&gain[(size_t)so_indices[cur.sb + e] * Z + z_take], so_data[cur.sb + e]);
+                if (lane == 0) {
+                    slot[cur.k] = z_take;
+                    if (SLOT_LDS) slot_g[cur.k] = z_take;
+                }
+            } else if (lane == 0) {
+                atomicAdd(&unassigned, 1);
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        start = next;
+    }
+    if (threadIdx.x == 0) rem[b] = unassigned;
+}
+
 }  // namespace mmw

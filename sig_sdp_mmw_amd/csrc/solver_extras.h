@@ -17,7 +17,7 @@ template <typename T> struct Extras {
     DevBuf<double> so_data, h_max, so_hmax;  // so_hmax[e] = h_max[so_indices[e]]: the greedy reads it like so_data
     DevBuf<GreedyHdr> ghdr;
     DevBuf<double> gX, randv, P, gain, nrm;
-    DevBuf<int> pref, slot, order, rem;
+    DevBuf<int> pref, slot, order, rem, glag;
     Factorizer<T> fac;
     // gap work
     DevBuf<T> g_x, g_l, g_y, g_e1, g_e2, g_r, g_vec, g_tm;
@@ -183,10 +183,32 @@ template <typename T> struct Extras {
                 maxq = std::max(maxq, H->q_indptr[k + 1] - H->q_indptr[k]);
             }
             maxdeg = (maxdeg + 1) / 2 * 2;  // keep the int arrays after the doubles 8-byte aligned
-            if (maxdeg > 4 * BLOCK || maxq > 4 * BLOCK || Z > 4 * BLOCK)
-                return fail(MMW_ERR_ARG, "mmw_round: more than 1024 neighbours / slots per user is not supported by the greedy kernel");
-            const size_t base = (size_t)2 * ((size_t)maxdeg * 20 + (size_t)maxq * 4 + (size_t)Z * 4) + (size_t)Z * 4;
+            if (getenv("MMW_GREEDY_SEQ") && (maxdeg > 4 * BLOCK || maxq > 4 * BLOCK || Z > 4 * BLOCK))
+                return fail(MMW_ERR_ARG, "mmw_round: more than 1024 neighbours / slots per user is not supported by the sequential greedy kernel");
             hipLaunchKernelGGL(k_greedy_headers, dim3(grid_elems((size_t)K)), dim3(BLOCK), 0, st, K, order.p, so_indptr.p, q_indptr.p, h_max.p, ghdr.p);
+            static const bool sequential = getenv("MMW_GREEDY_SEQ") != nullptr;  // the one-user-per-step kernel, kept for comparison
+            if (!sequential) {
+                // several mutually non-interacting users per step (k_greedy_b): interaction lags of the visiting order first
+                MMW_TRY(ensure(glag, (size_t)K));
+                MMW_HIP(hipMemsetAsync(glag.p, 0x7F, (size_t)K * sizeof(int), st));
+                const size_t pairs = (size_t)K * (GB_WAVES - 1);
+                hipLaunchKernelGGL(k_greedy_conflicts, dim3((unsigned)((pairs + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, K, (const GreedyHdr*)ghdr.p,
+                                   so_indices.p, q_indices.p, glag.p);
+                const size_t baseb = (size_t)GB_WAVES * Z * 4 + (((size_t)K + 3) & ~(size_t)3);
+                if (baseb > 150 * 1024) return fail(MMW_ERR_ARG, "mmw_round: K + 32 Z bytes exceed the greedy kernel's LDS");
+                const bool slot_lds = baseb + (size_t)K * 4 <= 150 * 1024;
+                const size_t sh = baseb + (slot_lds ? (size_t)K * 4 : 0);
+                if (slot_lds) {
+                    MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_greedy_b<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+                    hipLaunchKernelGGL((k_greedy_b<true>), dim3(nb), dim3(GB_WAVES * 64), sh, st, K, Z, (const GreedyHdr*)ghdr.p, (const int*)glag.p, pref.p,
+                                       so_indices.p, so_data.p, so_hmax.p, q_indices.p, gain.p, slot.p, rem.p);
+                } else {
+                    MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_greedy_b<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+                    hipLaunchKernelGGL((k_greedy_b<false>), dim3(nb), dim3(GB_WAVES * 64), sh, st, K, Z, (const GreedyHdr*)ghdr.p, (const int*)glag.p, pref.p,
+                                       so_indices.p, so_data.p, so_hmax.p, q_indices.p, gain.p, slot.p, rem.p);
+                }
+            } else {
+            const size_t base = (size_t)2 * ((size_t)maxdeg * 20 + (size_t)maxq * 4 + (size_t)Z * 4) + (size_t)Z * 4;
             const bool slot_lds = base + (size_t)K * 4 <= 150 * 1024;
             const size_t sh = base + (slot_lds ? (size_t)K * 4 : 0);
             if (sh > 160 * 1024) return fail(MMW_ERR_ARG, "mmw_round: a user's neighbour list does not fit the greedy kernel's LDS record");
@@ -198,6 +220,7 @@ template <typename T> struct Extras {
                 MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_greedy<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
                 hipLaunchKernelGGL((k_greedy<false>), dim3(nb), dim3(BLOCK), sh, st, K, Z, maxdeg, maxq, (const GreedyHdr*)ghdr.p, pref.p, so_indices.p,
                                    so_data.p, so_hmax.p, q_indices.p, gain.p, slot.p, rem.p);
+            }
             }
         }
         if (kt) MMW_TRY(kt->end());
