@@ -188,6 +188,7 @@ template <typename T> struct Factorizer {
     DevBuf<double> partial, colsum, rho_part, out64;
     std::vector<double> last;    // [K*rank]
     int last_rank = 0;
+
     int outer_done = 0;
     double last_resid = 0.0;
 
@@ -283,7 +284,18 @@ template <typename T> struct Factorizer {
             // ---- Rayleigh-Ritz on span(V)
             MMW_TRY((spmm<SPMM_PLAIN>(lay, nblk, indptr, col, val, V.p, W.p, nullptr, nullptr, ascale, 0.0, 0.0)));
             MMW_TRY(dw.gram(K, b, ld, V.p, W.p, true));
-            MMW_TRY(dw.jacobi(b, f32 ? 1e-8 : 1e-13, 30));
+            // A random start block spans nothing of interest yet: its Rayleigh quotients (the diagonal of G) are all the first
+            // filter needs, and the dense eigensolve of a random projection is the most expensive one of the run (b > 96: ~10
+            // Jacobi sweeps of b - 1 launches each).
+            // (Seeding the block with the previous probe's Ritz vectors was tried: the averaged X of neighbouring slot counts
+            // do not share their leading subspace -- first residual 0.2 either way -- so every call starts from a random block.)
+            const bool skip_rr = outer == 0 && b > JAC_LDS_MAX && b < K && !getenv("MMW_FACTOR_FULL_RR");
+            if (skip_rr) {
+                hipLaunchKernelGGL(k_set_eye, dim3(grid_elems((size_t)b * b)), dim3(BLOCK), 0, st, b, dw.Q.p);
+                hipLaunchKernelGGL(k_get_diag, dim3(grid_elems(b)), dim3(BLOCK), 0, st, b, dw.G.p, dw.diag.p);
+            } else {
+                MMW_TRY(dw.jacobi(b, f32 ? 1e-8 : 1e-13, 30));
+            }
             MMW_HIP(hipMemcpyAsync(theta.data(), dw.diag.p, b * sizeof(double), hipMemcpyDeviceToHost, st));
             MMW_HIP(hipStreamSynchronize(st));
             std::iota(perm.begin(), perm.end(), 0);
@@ -314,7 +326,7 @@ template <typename T> struct Factorizer {
             const double scale_top = std::max(std::fabs(theta[0]), 1e-300);
             last_resid = worst / scale_top;
             if (getenv("MMW_FACTOR_VERBOSE")) fprintf(stderr, "[factor]   outer %d degree %d resid %.2e\n", outer, degree, last_resid);
-            if (b >= K || last_resid <= tol) {
+            if (!skip_rr && (b >= K || last_resid <= tol)) {
                 done = true;
                 break;
             }
@@ -324,7 +336,7 @@ template <typename T> struct Factorizer {
             cut = std::max(cut, 1e-12 * mu_top);
             cut = std::min(cut, 0.999 * theta[rank - 1] * theta[rank - 1] + 1e-300);
             const double e = 0.5 * cut, cen = 0.5 * cut;
-            const double a0 = std::max(mu_top, rho * rho * 1e-30);
+            const double a0 = skip_rr ? rho * rho : std::max(mu_top, rho * rho * 1e-30);  // no Ritz values yet: the 1-norm bounds the spectrum
             double sigma1 = e / (a0 - cen), sigma = sigma1;
             // Y = sigma1/e (B V - cen V): T1 = A V (already W); Ycur = c1 * A W + c2 * V
             MMW_TRY((spmm<SPMM_AXPBY>(lay, nblk, indptr, col, val, W.p, Y1.p, V.p, V.p, ascale * sigma1 / e, -cen * sigma1 / e, 0.0)));
@@ -379,6 +391,7 @@ template <typename T> struct Factorizer {
         MMW_HIP(hipMemcpyAsync(last.data(), out64.p, (size_t)K * rank * sizeof(double), hipMemcpyDeviceToHost, st));
         MMW_HIP(hipStreamSynchronize(st));
         last_rank = rank;
+
         // restore the unit column scales used by k_select_cols
         if (out) memcpy(out, last.data(), last.size() * sizeof(double));
         return MMW_OK;
