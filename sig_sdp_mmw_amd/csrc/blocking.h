@@ -151,7 +151,8 @@ inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& i
             return;
     for (int k = 0; k < K; ++k)
         if (indptr[k + 1] - indptr[k] > BLK_UNION) return;  // a single row overflows the tile: generic kernel
-    const std::vector<int32_t> rcm = rcm_order(K, indptr, indices);
+    if (B.rcm_cache.size() != (size_t)K) B.rcm_cache = rcm_order(K, indptr, indices);  // the caller may have made it already
+    const std::vector<int32_t>& rcm = B.rcm_cache;
     std::vector<int32_t> rank(K);
     for (int p = 0; p < K; ++p) rank[rcm[p]] = p;
     // Row blocks.  Seeds sweep the RCM order; a block then GROWS from its seed: the next row is the unassigned member of the
@@ -397,7 +398,6 @@ inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& i
         if (blk2_lds_need(d[5], d[3], lim.entry_bytes) > BLK2_LDS_BYTES) B.fits_half_tile = false;
     }
     B.usable = B.reuse >= 2.0 && fits_full;
-    B.rcm_cache = rcm;
 }
 
 // Row blocks for the matrix-core SpMM (kernels_mfma.h): grown like the blocks above (seed = next unassigned row of the RCM

@@ -4,6 +4,8 @@
 #include <map>
 #include <queue>
 #include <memory>
+#include <atomic>
+#include <thread>
 
 #include "blocking.h"
 #include "expm_engine.h"
@@ -109,6 +111,20 @@ template <typename T> struct Solver final : mmw_solver {
         const bool verbose = getenv("MMW_VERBOSE") != nullptr;
         auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         const double t_0 = tnow();
+        // The first kernel launch of a process loads the library's code object (~0.15 s): start it on a helper thread now, under
+        // the host-side pattern build.
+        static std::atomic<bool> module_loading{false};
+        std::thread warm_thread;
+        if (!host_only && !module_loading.exchange(true))
+            warm_thread = std::thread([dev]() {
+                if (hipSetDevice(dev) != hipSuccess) return;
+                float* p = nullptr;
+                if (hipMalloc((void**)&p, 256 * sizeof(float)) != hipSuccess) return;
+                hipLaunchKernelGGL((k_fill<float>), dim3(1), dim3(BLOCK), 0, (hipStream_t) nullptr, (size_t)256, p, 0.0f);
+                (void)hipDeviceSynchronize();
+                (void)hipFree(p);
+            });
+        struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{warm_thread};
         std::string err = build_pattern(H, K_, Z_, Sp, Si, Sx, Qp, Qi, Qx, h);
         const double t_1 = tnow();
         if (!err.empty()) return fail(MMW_ERR_ARG, "mmw_create: " + err);
@@ -201,7 +217,20 @@ template <typename T> struct Solver final : mmw_solver {
         const char* env = getenv("MMW_BLOCKING");
         if (env && env[0] == '0') blocking_mode = 0;
         if (!blocking_mode) return MMW_OK;
-        build_blocking(HB, K, H.l_indptr, H.l_indices, blocking_limits<T>());
+        {   // both blockings start from the same RCM order and fill disjoint parts of HB: two host threads
+            const bool want_mf = sizeof(T) == 4 && !getenv("MMW_NO_MFMA") && (double)K * eng.lay.Dpad * 4.0 < 4.0e9;
+            bool rows_ok = true;
+            for (int k = 0; k < K && rows_ok; ++k) rows_ok = H.l_indptr[k + 1] - H.l_indptr[k] <= BLK_UNION;
+            if (rows_ok) HB.rcm_cache = rcm_order(K, H.l_indptr, H.l_indices);
+            const int mrows = getenv("MMW_MF_ROWS") ? atoi(getenv("MMW_MF_ROWS")) : 64;
+            std::thread mf_thread;
+            if (want_mf && rows_ok) mf_thread = std::thread([&]() { build_mfma_blocking(HB, K, H.l_indptr, H.l_indices, std::min(64, std::max(1, mrows))); });
+            build_blocking(HB, K, H.l_indptr, H.l_indices, blocking_limits<T>());
+            if (mf_thread.joinable()) mf_thread.join();
+            if (want_mf && getenv("MMW_VERBOSE"))
+                fprintf(stderr, "[mmw] matrix-core blocking: ok %d blocks %d rows/block %.1f reuse %.2f row tiles %d k-steps %d\n", (int)HB.fits_mfma, HB.nbm(),
+                        (double)K / std::max(1, HB.nbm()), HB.m_reuse, HB.mfma_mt, HB.kbase.empty() ? 0 : HB.kbase.back());
+        }
         if (getenv("MMW_VERBOSE"))
             fprintf(stderr, "[mmw] blocking: usable %d half-tile %d blocks %d rows/block %.1f union/block %.1f entries %lld (nnz %lld, +%.1f%% padding) sd_max %d\n",
                     (int)HB.usable, (int)HB.fits_half_tile, HB.nb(), (double)K / std::max(1, HB.nb()), (double)HB.un_cols.size() / std::max(1, HB.nb()),
@@ -250,13 +279,6 @@ template <typename T> struct Solver final : mmw_solver {
             MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sddmm_blk2<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         std::max(HB.un8_max * B2_ROW_BYTES, 65536)));
             sddmm_blk2 = true;
-        }
-        if (sizeof(T) == 4 && !getenv("MMW_NO_MFMA") && (double)K * eng.lay.Dpad * 4.0 < 4.0e9) {
-            const int mrows = getenv("MMW_MF_ROWS") ? atoi(getenv("MMW_MF_ROWS")) : 64;
-            build_mfma_blocking(HB, K, H.l_indptr, H.l_indices, std::min(64, std::max(1, mrows)));
-            if (getenv("MMW_VERBOSE"))
-                fprintf(stderr, "[mmw] matrix-core blocking: ok %d blocks %d rows/block %.1f reuse %.2f row tiles %d k-steps %d\n", (int)HB.fits_mfma, HB.nbm(),
-                        (double)K / std::max(1, HB.nbm()), HB.m_reuse, HB.mfma_mt, HB.kbase.empty() ? 0 : HB.kbase.back());
         }
         if (sizeof(T) == 4 && HB.fits_mfma) {
             MMW_TRY(b_kbase.upload(HB.kbase, st));

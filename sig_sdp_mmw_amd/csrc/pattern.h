@@ -96,6 +96,10 @@ static inline std::string build_pattern(HostPattern& P, int32_t K, int32_t Z, co
     // and its transpose S_T' by a counting pass.
     std::vector<int32_t> f_indptr(K + 1, 0), f_indices;
     std::vector<double> f_data;
+    f_indices.reserve((size_t)Sp[K]);
+    f_data.reserve((size_t)Sp[K]);
+    P.so_indices.reserve((size_t)Sp[K]);
+    P.so_data.reserve((size_t)Sp[K]);
     P.so_indptr.assign(K + 1, 0);
     std::vector<int32_t> cnt(K + 1, 0);
     for (int32_t j = 0; j < K; ++j) {
@@ -166,6 +170,10 @@ static inline std::string build_pattern(HostPattern& P, int32_t K, int32_t Z, co
     // ---- L pattern rows: merge {a}, S_T' row a, filtered-S row a, Q row a
     P.l_indptr.assign(K + 1, 0);
     P.diag_pos.assign(K, -1);
+    {
+        const size_t cap = (size_t)2 * (size_t)nst + (size_t)Qp[K] + (size_t)K;
+        P.l_indices.reserve(cap); P.sab.reserve(cap); P.sba.reserve(cap); P.pid.reserve(cap);
+    }
     for (int32_t a = 0; a < K; ++a) {
         int32_t i1 = P.st_indptr[a], e1 = P.st_indptr[a + 1];  // S_T'[a, .]
         int32_t i2 = f_indptr[a], e2 = f_indptr[a + 1];        // S_T'[., a] (filtered S row a)
@@ -201,24 +209,30 @@ static inline std::string build_pattern(HostPattern& P, int32_t K, int32_t Z, co
     }
     const int64_t nnz = P.nnzL();
     if (nnz > (int64_t)INT32_MAX) return "pattern too large for int32 indexing";
-    // ---- mirrors, edge lists
+    // ---- mirrors, edge lists.  The pattern is symmetric and every row is sorted, so while the rows a are swept in ascending
+    // order the entries (b, a) of any row b are met in that row's own order: one cursor per row replaces a binary search per entry.
     P.mirror.assign(nnz, -1);
     P.asso_pos.assign(P.asso_x.size(), -1);
-    for (int32_t a = 0; a < K; ++a)
-        for (int32_t e = P.l_indptr[a]; e < P.l_indptr[a + 1]; ++e) {
-            const int32_t b = P.l_indices[e];
-            int32_t w;
-            if (!row_has(P.l_indices.data(), P.l_indptr[b], P.l_indptr[b + 1], a, &w)) return "internal: asymmetric pattern";
-            P.mirror[e] = w;
-            if (b > a) {
-                if (P.pid[e] >= 0) {
-                    P.asso_pos[P.pid[e]] = e;
-                } else {
-                    P.gain_x.push_back(a);
-                    P.gain_y.push_back(b);
+    P.gain_x.reserve((size_t)nnz / 2);
+    P.gain_y.reserve((size_t)nnz / 2);
+    {
+        std::vector<int32_t> cursor(P.l_indptr.begin(), P.l_indptr.end() - 1);
+        for (int32_t a = 0; a < K; ++a)
+            for (int32_t e = P.l_indptr[a]; e < P.l_indptr[a + 1]; ++e) {
+                const int32_t b = P.l_indices[e];
+                const int32_t w = cursor[b]++;
+                if (w >= P.l_indptr[b + 1] || P.l_indices[w] != a) return "internal: asymmetric pattern";
+                P.mirror[e] = w;
+                if (b > a) {
+                    if (P.pid[e] >= 0) {
+                        P.asso_pos[P.pid[e]] = e;
+                    } else {
+                        P.gain_x.push_back(a);
+                        P.gain_y.push_back(b);
+                    }
                 }
             }
-        }
+    }
     return "";
 }
 
