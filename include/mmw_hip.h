@@ -178,6 +178,30 @@ int mmw_expm_apply(int device, int dtype, int method, int max_order, double tol,
 int mmw_round(mmw_solver* s, int32_t Zr, int32_t Dp, const double* gX, int32_t nbatch, const double* randv,
               int32_t* z_out, int32_t* rem_out);
 
+/*
+ * The producer and the consumer either side of the path, on the device.
+ *
+ * mmw_env_create: env._compute_txp / _compute_state / generate_S_Q_hmax (sim_src/env/env.py:136-196) for K stations at
+ * sta_xy[K][2] and A access points at ap_xy[A][2] (the caller draws the station drop, env.py:59): path loss
+ * 20 log10(f/1e6) - 12 + 28 log10(d + 1) dB, transmit power so that the strongest AP receives txp_offset * min_sinr over the
+ * noise floor, receive powers below min_s_n_ratio dropped, association = strongest AP; S_gain = rx[:, asso] without explicit
+ * zeros, Q_asso = same-AP relation without diagonal, h_max = diag(S_gain) / min_sinr - 1, all as CSR built on the device.
+ * mmw_env_sizes: out = {K, A, nnz(S_gain), nnz(Q_asso)}; mmw_env_state copies the CSR arrays (caller-sized from mmw_env_sizes)
+ * and h_max[K] to the host -- exactly the `state` mmw_create takes.
+ * mmw_env_evaluate: env.evaluate_sinr / evaluate_bler (env.py:198-233) for the colouring z_vec[K] (float64 slot numbers as
+ * rounding returns them) with Z slots: sinr_out[K] after the one-survivor rule for users of one AP sharing a slot, and, when
+ * bler_out is not NULL, the finite-blocklength block error rate (env.py:107-111) per user.
+ */
+typedef struct mmw_env mmw_env;
+int mmw_env_create(mmw_env** out, int device, int32_t K, int32_t A, const double* sta_xy, const double* ap_xy, double fre_Hz,
+                   double txp_offset, double min_s_n_ratio, double min_sinr, double noise_floor_dbm);
+int mmw_env_destroy(mmw_env* e);
+int mmw_env_sizes(mmw_env* e, int64_t out[4]);
+int mmw_env_state(mmw_env* e, int32_t* S_indptr, int32_t* S_indices, double* S_data, int32_t* Q_indptr, int32_t* Q_indices,
+                  double* Q_data, double* h_max);
+int mmw_env_evaluate(mmw_env* e, const double* z_vec, int32_t Z, double packet_bit, double bandwidth, double slot_time,
+                     double* sinr_out, double* bler_out);
+
 #ifdef __cplusplus
 }
 #endif

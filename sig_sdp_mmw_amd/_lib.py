@@ -22,7 +22,8 @@ I_L_INDPTR, I_L_INDICES, I_ST_INDPTR, I_ST_INDICES, I_GAIN_X, I_GAIN_Y, I_ASSO_X
 
 EXPORTS = ["mmw_last_error", "mmw_version", "mmw_device_count", "mmw_create", "mmw_destroy", "mmw_sizes", "mmw_set_expm",
            "mmw_set_timing", "mmw_set_profile", "mmw_bench_spmm", "mmw_reset", "mmw_set_slots", "mmw_set_slots_warm", "mmw_set_eta", "mmw_iterate", "mmw_sync", "mmw_read_f64", "mmw_read_i32", "mmw_gap",
-           "mmw_factor", "mmw_expm_apply", "mmw_round"]
+           "mmw_factor", "mmw_expm_apply", "mmw_round", "mmw_env_create", "mmw_env_destroy", "mmw_env_sizes", "mmw_env_state",
+           "mmw_env_evaluate"]
 
 
 class MMWError(RuntimeError):
@@ -68,6 +69,12 @@ def lib():
     L.mmw_expm_apply.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int32, C.c_int32, p_i32, p_i32, p_f64,
                                  p_f64, p_f64, p_f64, C.c_int32, p_f64]
     L.mmw_round.argtypes = [C.c_void_p, C.c_int32, C.c_int32, p_f64, C.c_int32, p_f64, p_i32, p_i32]
+    L.mmw_env_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int32, C.c_int32, p_f64, p_f64, C.c_double, C.c_double, C.c_double, C.c_double,
+                                 C.c_double]
+    L.mmw_env_destroy.argtypes = [C.c_void_p]
+    L.mmw_env_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    L.mmw_env_state.argtypes = [C.c_void_p, p_i32, p_i32, p_f64, p_i32, p_i32, p_f64, p_f64]
+    L.mmw_env_evaluate.argtypes = [C.c_void_p, p_f64, C.c_int32, C.c_double, C.c_double, C.c_double, p_f64, p_f64]
     for name in EXPORTS:
         if name not in ("mmw_last_error",):
             getattr(L, name).restype = C.c_int
@@ -271,6 +278,56 @@ class Solver:
         rem = np.empty(nb, dtype=np.int32)
         check(lib().mmw_round(self._h, int(Z), int(Dp), _pd(gX), int(nb), _pd(randv), _pi(z), _pi(rem)))
         return z, rem
+
+
+class DeviceEnv:
+    """Owning wrapper of one `mmw_env*`: the reference's problem generator and scorer on the device (env.py:136-233)."""
+
+    def __init__(self, sta_locs, ap_locs, fre_Hz=4e9, txp_offset=2.0, min_s_n_ratio=0.1, min_sinr=1.0, noise_floor_dbm=-94.0, device=0):
+        sta = _f64(sta_locs)
+        ap = _f64(ap_locs)
+        if sta.ndim != 2 or sta.shape[1] != 2 or ap.ndim != 2 or ap.shape[1] != 2:
+            raise MMWError("station and AP locations must be (n, 2) arrays")
+        self.K, self.A = int(sta.shape[0]), int(ap.shape[0])
+        self._h = C.c_void_p()
+        check(lib().mmw_env_create(C.byref(self._h), int(device), self.K, self.A, _pd(sta), _pd(ap), float(fre_Hz), float(txp_offset),
+                                   float(min_s_n_ratio), float(min_sinr), float(noise_floor_dbm)))
+        sz = (C.c_int64 * 4)()
+        check(lib().mmw_env_sizes(self._h, sz))
+        self.nnzS, self.nnzQ = int(sz[2]), int(sz[3])
+
+    def state(self):
+        """(S_gain csr, Q_asso csr, h_max) as env.generate_S_Q_hmax returns them."""
+        import scipy.sparse
+        sp = np.empty(self.K + 1, dtype=np.int32); si = np.empty(self.nnzS, dtype=np.int32); sx = np.empty(self.nnzS, dtype=np.float64)
+        qp = np.empty(self.K + 1, dtype=np.int32); qi = np.empty(self.nnzQ, dtype=np.int32); qx = np.empty(self.nnzQ, dtype=np.float64)
+        h = np.empty(self.K, dtype=np.float64)
+        check(lib().mmw_env_state(self._h, _pi(sp), _pi(si), _pd(sx), _pi(qp), _pi(qi), _pd(qx), _pd(h)))
+        S = scipy.sparse.csr_matrix((sx, si, sp), shape=(self.K, self.K))
+        Q = scipy.sparse.csr_matrix((qx, qi, qp), shape=(self.K, self.K))
+        return S, Q, h
+
+    def evaluate(self, z, Z, packet_bit=800, bandwidth=5e6, slot_time=1.25e-4, bler=True):
+        """(sinr, bler) per user under the colouring z (env.evaluate_sinr / evaluate_bler)."""
+        zz = _f64(z)
+        if zz.shape != (self.K,):
+            raise MMWError("z must have one slot per user")
+        sinr = np.empty(self.K, dtype=np.float64)
+        bl = np.empty(self.K, dtype=np.float64) if bler else None
+        check(lib().mmw_env_evaluate(self._h, _pd(zz), int(Z), float(packet_bit), float(bandwidth), float(slot_time), _pd(sinr),
+                                     _pd(bl) if bler else None))
+        return sinr, bl
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().mmw_env_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def expm_apply(A_csr, B, dtype=F64, method=EXPM_LANCZOS, max_order=12, tol=1e-9, device=0, reps=1):

@@ -8,6 +8,7 @@
 #include <thread>
 
 #include "blocking.h"
+#include "env_device.h"
 #include "expm_engine.h"
 #include "kernels_loop.h"
 #include "pattern.h"
@@ -1067,6 +1068,45 @@ int mmw_expm_apply(int device, int dtype, int method, int max_order, double tol,
     if (dtype == MMW_F32) return expm_apply_impl<float>(device, method, max_order, tol, K, D, indptr, indices, data, B, out, info, reps, kernel_us);
     if (dtype == MMW_F64) return expm_apply_impl<double>(device, method, max_order, tol, K, D, indptr, indices, data, B, out, info, reps, kernel_us);
     return fail(MMW_ERR_ARG, "dtype must be MMW_F32 or MMW_F64");
+}
+
+
+// ---- problem generator and scorer on the device (include/mmw_hip.h) ----------------------------------------
+struct mmw_env {
+    mmw::EnvDevice e;
+};
+int mmw_env_create(mmw_env** out, int device, int32_t K, int32_t A, const double* sta_xy, const double* ap_xy, double fre_Hz, double txp_offset,
+                   double min_s_n_ratio, double min_sinr, double noise_floor_dbm) {
+    if (!out || !sta_xy || !ap_xy) return fail(MMW_ERR_ARG, "mmw_env_create: null pointer");
+    *out = nullptr;
+    if (K < 1 || A < 1) return fail(MMW_ERR_ARG, "mmw_env_create: K and A must be positive");
+    if (!(min_sinr > 0.0) || !(txp_offset > 0.0) || !(fre_Hz > 0.0)) return fail(MMW_ERR_ARG, "mmw_env_create: min_sinr, txp_offset and fre_Hz must be positive");
+    int ndev = 0;
+    MMW_TRY(mmw_device_count(&ndev));
+    if (device < 0 || device >= ndev) return fail(MMW_ERR_HIP, "mmw_env_create: no such HIP device " + std::to_string(device) + " (" + std::to_string(ndev) + " visible)");
+    auto h = std::make_unique<mmw_env>();
+    const int rc = h->e.init(device, K, A, sta_xy, ap_xy, fre_Hz, txp_offset, min_s_n_ratio, min_sinr, noise_floor_dbm);
+    if (rc == MMW_OK) *out = h.release();
+    return rc;
+}
+int mmw_env_destroy(mmw_env* e) {
+    delete e;
+    return MMW_OK;
+}
+int mmw_env_sizes(mmw_env* e, int64_t out[4]) {
+    if (!e || !out) return fail(MMW_ERR_ARG, "null pointer");
+    out[0] = e->e.K; out[1] = e->e.A; out[2] = e->e.nnzS; out[3] = e->e.nnzQ;
+    return MMW_OK;
+}
+int mmw_env_state(mmw_env* e, int32_t* S_indptr, int32_t* S_indices, double* S_data, int32_t* Q_indptr, int32_t* Q_indices, double* Q_data,
+                  double* h_max) {
+    if (!e || !S_indptr || !S_indices || !S_data || !Q_indptr || !Q_indices || !Q_data || !h_max) return fail(MMW_ERR_ARG, "mmw_env_state: null pointer");
+    return e->e.state(S_indptr, S_indices, S_data, Q_indptr, Q_indices, Q_data, h_max);
+}
+int mmw_env_evaluate(mmw_env* e, const double* z_vec, int32_t Z, double packet_bit, double bandwidth, double slot_time, double* sinr_out,
+                     double* bler_out) {
+    if (!e || !z_vec || !sinr_out) return fail(MMW_ERR_ARG, "mmw_env_evaluate: null pointer");
+    return e->e.evaluate(z_vec, Z, packet_bit, bandwidth, slot_time, sinr_out, bler_out);
 }
 
 }  // extern "C"

@@ -23,7 +23,7 @@ import scipy.sparse
 import scipy.spatial.distance
 import scipy.stats
 
-__all__ = ["journal_graph", "er_contention_graph", "min_sinr_dec", "instance_stats"]
+__all__ = ["journal_graph", "journal_graph_device", "journal_geometry", "er_contention_graph", "min_sinr_dec", "instance_stats"]
 
 _NOISE_FLOOR_DBM = -94.0  # env.py:9
 
@@ -101,6 +101,29 @@ def journal_graph(cell_size=20, sta_density_per_1m2=5e-3, seed=1, cell_edge=20.0
     if return_geometry:
         return (S, Q, h_max), {"sta_locs": sta_locs, "ap_locs": ap_locs, "asso": asso}
     return S, Q, h_max
+
+
+def journal_geometry(cell_size=20, sta_density_per_1m2=5e-3, seed=1, cell_edge=20.0):
+    """AP grid and station drop of `env.__init__` (env.py:16-59): (sta_locs (K, 2), ap_locs (A, 2))."""
+    grid_edge = cell_edge * cell_size
+    n_sta = int(cell_size ** 2 * (sta_density_per_1m2 * cell_edge ** 2))
+    off = cell_edge / 2.0
+    ax = np.linspace(0 + off, grid_edge - off, cell_size)
+    xx, yy = np.meshgrid(ax, ax)
+    ap_locs = np.array((xx.ravel(), yy.ravel())).T
+    sta_locs = np.random.default_rng(seed).uniform(low=0.0, high=grid_edge, size=(n_sta, 2))
+    return sta_locs, ap_locs
+
+
+def journal_graph_device(cell_size=20, sta_density_per_1m2=5e-3, seed=1, cell_edge=20.0, fre_Hz=4e9, txp_offset=2.0, min_s_n_ratio=0.1,
+                         device=0):
+    """The same instance as `journal_graph`, generated on the GPU (`mmw_env_create`, csrc/env_device.h): the host only draws the
+    2 K station coordinates.  Returns (state, env) where `env` also scores colourings (`env.evaluate(z, Z)`)."""
+    from . import _lib
+    sta_locs, ap_locs = journal_geometry(cell_size, sta_density_per_1m2, seed, cell_edge)
+    env = _lib.DeviceEnv(sta_locs, ap_locs, fre_Hz=fre_Hz, txp_offset=txp_offset, min_s_n_ratio=min_s_n_ratio, min_sinr=min_sinr_dec(),
+                         noise_floor_dbm=_NOISE_FLOOR_DBM, device=device)
+    return env.state(), env
 
 
 def er_contention_graph(K, p, seed, clique=3, lo=0.1, hi=3.7, own_gain=None):
