@@ -4,6 +4,7 @@
 #pragma once
 #include <cmath>
 
+#include <functional>
 #include <type_traits>
 
 #include "kernels_expm.h"
@@ -214,6 +215,8 @@ template <typename T> struct ExpmEngine {
     bool mfma_now() const { return use_mfma && use_blk && std::is_same<T, float>::value && (lay.Dpad % 32) == 0 && last_mfma_ok; }
     int spmm_slabs() const { return mfma_now() ? mf.nb : npart; }  // partial slabs the next SpMM launch writes
     bool last_mfma_ok = true;    // what the last plan the host has seen said (the matrix starts at zero)
+    bool* blk_stale = nullptr;   // owner's flag: val_blk lags the CSR values
+    std::function<int()> blk_refresh;  // rebuilds val_blk from the CSR values
     T* rownorm_d = nullptr;      // optional: the combination also emits ||y_row||^2 and its per-block sums (nblk slabs)
     double* rownorm_part = nullptr;
     bool start_colsq_ready = false;  // the producer of the start block already filled `partial` with its column sums of squares (npart_start slabs)
@@ -327,6 +330,10 @@ template <typename T> struct ExpmEngine {
                 return kend();
             }
         }
+        if (use_blk && blk_stale && *blk_stale) {  // the owner left the blocked copy of the values behind while the matrix cores ran
+            MMW_TRY(blk_refresh());
+            *blk_stale = false;
+        }
         MMW_TRY(kbegin(KT_SPMM));
         if (use_blk)
             MMW_TRY((spmm_blk_launch<T, MODE>(st, blk, lay.Dpad, val_blk, in, out, F, nullptr, ascale, shift, inv_k, partial.p, plan, step,
@@ -426,9 +433,13 @@ template <typename T> struct ExpmEngine {
                     planes_ready[j - 1] = false;  // consumed; the block is rewritten by the next application
                     MMW_TRY(kbegin(KT_KRYLOV_VEC));
                     // one launch: the norms of U_j, alpha_j, and after the last product the small exponentials
-                    hipLaunchKernelGGL(k_lz_scalars, dim3((Dpad + LZS_COLS - 1) / LZS_COLS), dim3(1024), 0, st, mf_step ? mf.nb : npart, partial.p,
-                                       apost() ? partial_o2.p : (double*)nullptr, nsq, partial_sq.p, Dpad, j, m,
-                                       1.0 / nsub, eps, S, pd);
+#define MMW_LZS(NMAX)                                                                                                               \
+    hipLaunchKernelGGL((k_lz_scalars<NMAX>), dim3((Dpad + LZS_COLS - 1) / LZS_COLS), dim3(1024), 0, st, mf_step ? mf.nb : npart, partial.p, \
+                       apost() ? partial_o2.p : (double*)nullptr, nsq, partial_sq.p, Dpad, j, m, 1.0 / nsub, eps, S, pd)
+                    if (j + 2 <= 4) MMW_LZS(4);
+                    else if (j + 2 <= 8) MMW_LZS(8);
+                    else MMW_LZS(MAX_ORDER + 2);
+#undef MMW_LZS
                     if (kt && kt->on && apost() && j < m) {  // profiling counts exact launches: look at the estimate before going on
                         MMW_TRY(kend());
                         MMW_HIP(hipMemcpyAsync(plan_h, plan_d.p, sizeof(ExpmPlan), hipMemcpyDeviceToHost, st));

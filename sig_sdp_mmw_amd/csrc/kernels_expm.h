@@ -1045,6 +1045,10 @@ __device__ __forceinline__ double texp_order1(int Dpad, int c, double inv_nsub, 
 //   partA  holds the alpha numerators U_j . A U_j of the product just made        -> alpha_j
 // and, on the last step (j == m), the small exponentials (texp_core) of the columns this workgroup owns.
 constexpr int LZS_COLS = 4;  // columns per workgroup: 32-byte slab segments, 256 slab slices in flight per column
+// NMAX bounds the small exponentials this instantiation can run (steps j <= NMAX - 2): the host picks 4, 8 or MAX_ORDER + 2 by
+// the step number, so the common one- and two-step launches keep their five small vectors in registers (one kernel for every
+// order kept 18-entry arrays with dynamic bounds in scratch memory: 387 scratch instructions, 11 us per launch).
+template <int NMAX>
 __global__ __launch_bounds__(1024) void k_lz_scalars(int nbA, const double* __restrict__ partA, const double* __restrict__ partO2, int nbB,
                                                      const double* __restrict__ partB, int Dpad, int j, int m, double inv_nsub, double eps,
                                                      LanczosScalars S, ExpmPlan* __restrict__ plan) {
@@ -1114,9 +1118,7 @@ __global__ __launch_bounds__(1024) void k_lz_scalars(int nbA, const double* __re
     if (!apost) {
         if (j == mlast) {
             __threadfence_block();
-            if (j + 2 <= 4) texp_core<4>(Dpad, c, j, inv_nsub, S, scale, false);
-            else if (j + 2 <= 8) texp_core<8>(Dpad, c, j, inv_nsub, S, scale, false);
-            else texp_core<MAX_ORDER + 2>(Dpad, c, j, inv_nsub, S, scale, false);
+            texp_core<NMAX>(Dpad, c, j, inv_nsub, S, scale, false);
         }
         return;
     }
@@ -1128,9 +1130,7 @@ __global__ __launch_bounds__(1024) void k_lz_scalars(int nbA, const double* __re
     __threadfence_block();
     double phi2;
     if (j == 1) phi2 = texp_order1(Dpad, c, inv_nsub, S, scale);
-    else if (j + 2 <= 4) phi2 = texp_core<4>(Dpad, c, j, inv_nsub, S, scale, true);
-    else if (j + 2 <= 8) phi2 = texp_core<8>(Dpad, c, j, inv_nsub, S, scale, true);
-    else phi2 = texp_core<MAX_ORDER + 2>(Dpad, c, j, inv_nsub, S, scale, true);
+    else phi2 = texp_core<NMAX>(Dpad, c, j, inv_nsub, S, scale, true);
     const double n2 = si * si * to;
     double bj2 = n2 - alpha * alpha - bprev * bprev;
     const double floor2 = 4.0 * eps * n2;  // cancellation floor of the difference (the products were rounded to T)

@@ -71,12 +71,13 @@ template <typename T> struct Solver final : mmw_solver {
     uint64_t sketch_done_seed = 0;
     int sketch_done_slabs = 0;
     DevBuf<T> lval_blk;
+    bool lblk_stale = false;         // lval_blk lags lval (the matrix-core kernel ran the last products)
     DevBuf<int> b_kbase, b_fpos, b_mdesc, b_munfixed, b_morder;  // matrix-core SpMM: its row blocks, CSR entry -> fragment image position
     DevBuf<unsigned> afrag;          // the matrix as bf16 hi << 16 | lo words in MFMA fragment order
     size_t afrag_n = 0;
     int blocking_mode = 1;  // 1: use when profitable, 0: never
     // optimistic (no per-iteration readback) batches: snapshot for the rare replay
-    DevBuf<T> sn_lval, sn_lblk, sn_xval, sn_xavg, sn_Y, sn_yavg, sn_eaccu;
+    DevBuf<T> sn_lval, sn_xval, sn_xavg, sn_Y, sn_yavg, sn_eaccu;
     bool pending = false;
     int pend_iter0 = 0, pend_n = 0, m_guess = 3;
     size_t pend_events0 = 0;  // phase-timer events recorded before the pending chunk
@@ -305,6 +306,12 @@ template <typename T> struct Solver final : mmw_solver {
         }
         MMW_HIP(hipStreamSynchronize(st));
         extras.fac.set_blocking(blkdev(), b_bepos.p, HB.nent);
+        eng.blk_stale = &lblk_stale;
+        eng.blk_refresh = [this]() -> int {
+            hipLaunchKernelGGL((k_gather_blocked<T>), dim3(grid_elems((size_t)HB.nent)), dim3(BLOCK), 0, st, (size_t)HB.nent, b_bepos.p, lval.p, lval_blk.p);
+            MMW_HIP(hipGetLastError());
+            return MMW_OK;
+        };
         return eng.enable_blocking(blkdev(), lval_blk.p);
     }
 
@@ -547,6 +554,7 @@ template <typename T> struct Solver final : mmw_solver {
         if (lval_blk.p) MMW_HIP(hipMemsetAsync(lval_blk.p, 0, (size_t)HB.nent * sizeof(T), st));
         if (afrag.p) MMW_HIP(hipMemsetAsync(afrag.p, 0, afrag_n * sizeof(unsigned), st));
         eng.last_mfma_ok = true;
+        lblk_stale = false;
         MMW_HIP(hipMemsetAsync(xval.p, 0, nnz * sizeof(T), st));
         MMW_HIP(hipMemsetAsync(xavg.p, 0, nnz * sizeof(T), st));
         MMW_HIP(hipMemsetAsync(e_accu.p, 0, C * sizeof(T), st));
@@ -593,8 +601,9 @@ template <typename T> struct Solver final : mmw_solver {
             MMW_HIP(hipMemcpyAsync(save ? snap.p : live.p, save ? live.p : snap.p, n * sizeof(T), hipMemcpyDeviceToDevice, st));
             return MMW_OK;
         };
-        MMW_TRY(cp(sn_lval, lval, nnz)); MMW_TRY(cp(sn_lblk, lval_blk, lval_blk.p ? (size_t)HB.nent : 0)); MMW_TRY(cp(sn_xval, xval, nnz));
+        MMW_TRY(cp(sn_lval, lval, nnz)); MMW_TRY(cp(sn_xval, xval, nnz));
         MMW_TRY(cp(sn_xavg, xavg, nnz)); MMW_TRY(cp(sn_Y, Y, C)); MMW_TRY(cp(sn_yavg, yavg, C)); MMW_TRY(cp(sn_eaccu, e_accu, C));
+        if (!save && lval_blk.p) lblk_stale = true;  // rebuilt from the restored values when the fp32 kernel next needs it
         if (!save && afrag.p) {  // the fragment image follows the restored values
             hipLaunchKernelGGL((k_refrag<T>), dim3(grid_elems(nnz)), dim3(BLOCK), 0, st, nnz, lval.p, b_fpos.p, afrag.p);
             MMW_HIP(hipGetLastError());
@@ -711,8 +720,11 @@ template <typename T> struct Solver final : mmw_solver {
                 eng.planes_ready[0] = skl.planes != nullptr;
                 sketch_done_for = (int64_t)iter; sketch_done_seed = seed; sketch_done_slabs = skl.nblocks;
             }
+            // the blocked copy of L feeds the fp32 LDS kernel only: while the matrix-core kernel runs the products it is left stale
+            const bool mf_it = eng.mfma_now() && eng.method == MMW_EXPM_LANCZOS;
+            if (mf_it) lblk_stale = true;
             hipLaunchKernelGGL((k_loss<T>), dim3(gl + skl.nblocks), dim3(BLOCK), skl.nblocks && lz_m ? (size_t)WAVES_PER_BLOCK * Dpad * sizeof(double) : 0,
-                               st, P, d_lrow.p, Y.p, wH.p, scal.p, lval.p, eta, (const int*)(eng.use_blk ? b_bpos.p : nullptr), lval_blk.p,
+                               st, P, d_lrow.p, Y.p, wH.p, scal.p, lval.p, eta, (const int*)(eng.use_blk && !mf_it ? b_bpos.p : nullptr), lval_blk.p,
                                (const T*)(xavg_deferred ? xval.p : nullptr), xavg_deferred ? xavg.p : (T*)nullptr, skl, Dpad,
                                (const int*)(eng.use_mfma ? b_fpos.p : nullptr), afrag.p);
             xavg_deferred = false;
