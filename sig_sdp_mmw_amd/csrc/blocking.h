@@ -69,6 +69,14 @@ struct HostBlocking {
     // way (fewer, larger patches: each staged union row serves ~2x the nonzeros).  m_* mirror order / blk_rowptr / desc / un_fixed.
     std::vector<int32_t> m_order, m_rowptr, m_desc, m_unfixed;
     std::vector<int32_t> rcm_cache;     // the RCM order both blockings start from
+    // matrix-core SDDMM (k_sddmm_mfma): a block's rows x union product comes out in 32 x 32 tiles (row tile, union tile); the
+    // off-diagonal pattern entries of every tile, as (row in tile << 5 | column in tile) and CSR position.
+    // Tile index = m_tbase[b] + union tile * row tiles + row tile.
+    std::vector<int32_t> m_tbase;       // [nbm+1]
+    std::vector<int32_t> m_tptr;        // [tiles+1]
+    std::vector<uint16_t> m_trc;        // [off-diagonal nnz]
+    std::vector<int32_t> m_tepos;       // [off-diagonal nnz]
+    int m_ntile_max = 0;                // most union tiles of any block
     double m_reuse = 0.0;
     int nbm() const { return (int)m_rowptr.size() - 1; }
     int nb() const { return (int)blk_rowptr.size() - 1; }
@@ -487,6 +495,42 @@ inline void build_mfma_blocking(HostBlocking& B, int K, const std::vector<int32_
         }
         for (int u = un_ptr[b]; u < un_ptr[b + 1]; ++u) loc2[un_cols[u]] = -1;
     }
+    // tile lists of the SDDMM: counting pass, prefix, fill
+    B.m_tbase.assign(nbm + 1, 0);
+    B.m_ntile_max = 0;
+    for (int b = 0; b < nbm; ++b) {
+        const int nt = (un_ptr[b + 1] - un_ptr[b] + 31) / 32;
+        B.m_ntile_max = std::max(B.m_ntile_max, nt);
+        B.m_tbase[b + 1] = B.m_tbase[b] + nt * MT;
+    }
+    B.m_tptr.assign((size_t)B.m_tbase[nbm] + 1, 0);
+    for (int pass = 0; pass < 2; ++pass) {
+        std::vector<int32_t> fill;
+        if (pass == 1) {
+            for (size_t t = 0; t + 1 < B.m_tptr.size(); ++t) B.m_tptr[t + 1] += B.m_tptr[t];
+            fill.assign(B.m_tptr.begin(), B.m_tptr.end() - 1);
+            B.m_trc.assign((size_t)B.m_tptr.back(), 0);
+            B.m_tepos.assign((size_t)B.m_tptr.back(), -1);
+        }
+        for (int b = 0; b < nbm; ++b) {
+            for (int u = un_ptr[b]; u < un_ptr[b + 1]; ++u) loc2[un_cols[u]] = u - un_ptr[b];
+            for (int q = B.m_rowptr[b]; q < B.m_rowptr[b + 1]; ++q) {
+                const int r = B.m_order[q], rl = q - B.m_rowptr[b];
+                for (int e = indptr[r]; e < indptr[r + 1]; ++e) {
+                    if (indices[e] == r) continue;  // the diagonal comes from the exact row norms
+                    const int li = loc2[indices[e]];
+                    const int tile = B.m_tbase[b] + (li >> 5) * MT + (rl >> 5);
+                    if (pass == 0) ++B.m_tptr[(size_t)tile + 1];
+                    else {
+                        const int w = fill[tile]++;
+                        B.m_trc[w] = (uint16_t)(((rl & 31) << 5) | (li & 31));
+                        B.m_tepos[w] = e;
+                    }
+                }
+            }
+            for (int u = un_ptr[b]; u < un_ptr[b + 1]; ++u) loc2[un_cols[u]] = -1;
+        }
+    }
     B.fits_mfma = true;
 }
 
@@ -629,6 +673,26 @@ inline std::string verify_mfma_blocking(const HostBlocking& B, int K, const std:
     }
     for (int64_t e = 0; e < nnz; ++e)
         if (B.fpos[e] < 0) return "a CSR entry has no fragment position";
+    // SDDMM tile lists: every off-diagonal entry exactly once, in the tile its (row, union index) falls into
+    std::vector<char> seen_e((size_t)nnz, 0);
+    int64_t listed = 0;
+    for (int b = 0; b < nbm; ++b) {
+        const int32_t* d = &B.m_desc[(size_t)b * 8];
+        const int nun = d[5], nt = (nun + 31) / 32;
+        if (B.m_tbase[b + 1] - B.m_tbase[b] != nt * MT) return "tile count of a matrix-core block is off";
+        for (int t = B.m_tbase[b]; t < B.m_tbase[b + 1]; ++t) {
+            const int ut = (t - B.m_tbase[b]) / MT, mt = (t - B.m_tbase[b]) % MT;
+            for (int w = B.m_tptr[t]; w < B.m_tptr[t + 1]; ++w, ++listed) {
+                const int e = B.m_tepos[w], rl = 32 * mt + (B.m_trc[w] >> 5), li = 32 * ut + (B.m_trc[w] & 31);
+                if (e < 0 || e >= nnz || seen_e[e]) return "tile list holds a bad or repeated entry";
+                seen_e[e] = 1;
+                if (rl >= d[1] || li >= nun) return "tile list entry outside its block";
+                const int r = B.m_order[d[0] + rl];
+                if (e < indptr[r] || e >= indptr[r + 1] || indices[e] != B.m_unfixed[(size_t)b * MF_UNION + li] || indices[e] == r) return "tile list entry addresses the wrong (row, column)";
+            }
+        }
+    }
+    if (listed != nnz - K) return "the tile lists do not hold every off-diagonal entry";
     return "";
 }
 

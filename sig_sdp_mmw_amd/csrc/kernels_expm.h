@@ -1148,7 +1148,8 @@ template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_lz_combine(int K, int Dpad, int m, const T* __restrict__ Ubase, size_t stride,
                                                       const T* __restrict__ Tm, const double* __restrict__ coef, T* __restrict__ Yout,
                                                       ExpmPlan* __restrict__ plan, T* __restrict__ d,
-                                                      double* __restrict__ dpart, int* __restrict__ viol) {
+                                                      double* __restrict__ dpart, int* __restrict__ viol,
+                                                      unsigned short* __restrict__ planes = nullptr) {
     constexpr int VEC = V16<T>::N;
     __shared__ double sh[WAVES_PER_BLOCK];
     if (plan) {
@@ -1182,6 +1183,20 @@ __global__ __launch_bounds__(BLOCK) void k_lz_combine(int K, int Dpad, int m, co
                 ss += (double)x[v] * (double)x[v];
             }
             store16(Yout + o, x);
+            if constexpr (sizeof(T) == 4) {
+                if (planes) {  // the matrix-core SDDMM reads y as two bf16 halves (kernels_mfma.h)
+                    unsigned w4[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const float xf = x[v];
+                        const unsigned short hi = __builtin_bit_cast(unsigned short, (__bf16)xf);
+                        const unsigned short lo = __builtin_bit_cast(unsigned short, (__bf16)(xf - __uint_as_float((unsigned)hi << 16)));
+                        w4[v] = ((unsigned)hi << 16) | lo;
+                    }
+                    reinterpret_cast<uint2*>(planes)[o >> 2] = make_uint2((w4[0] >> 16) | (w4[1] & 0xFFFF0000u), (w4[2] >> 16) | (w4[3] & 0xFFFF0000u));
+                    reinterpret_cast<uint2*>(planes + (size_t)K * Dpad)[o >> 2] = make_uint2((w4[0] & 0xFFFFu) | (w4[1] << 16), (w4[2] & 0xFFFFu) | (w4[3] << 16));
+                }
+            }
         }
         if (d) {
             ss = wave_sum(ss);

@@ -361,4 +361,143 @@ void k_spmm_mfma(MfmaDev M, int Dpad, size_t plane_bytes, const char* __restrict
     }
 }
 
+
+// ---- X on the pattern (mmw.py:182-194) on the matrix cores ---------------------------------------------------------------------
+// The SDDMM of the same blocks: C = Y[rows] Y[union]^T as dense 32 x 32 tiles over the two bf16 halves of Y = exp(L/2) R
+// (written by the Lanczos combination), then only the pattern's entries of every tile are divided by the trace and stored.
+// Both operands are k-contiguous here (k runs along a row of Y), so fragments are plain 16-byte LDS reads, no transpose.
+// One workgroup = (row block, 4 union tiles = 128 union rows): 4 MT waves, wave (wm, wn) owns row tile wm x union tile wn.
+// A chunk = 32 columns of Y (2 k-steps, 64 bytes per row and plane) of the block's 32 MT rows and of the 128 union rows, brought
+// in by LDS-DMA like the SpMM's chunks; a row's four 16-byte slots are rotated by (row >> 2) -- applied on the DMA's source
+// side -- so that the 16 lanes of a ds_read_b128 service group, which read 16 different rows at the same slot, hit 16 different
+// bank quads.  The diagonal comes from the exact row norms the combination made (d / tr), not from the split product.
+// Error of an off-diagonal entry: <= 3 * 2^-17 |y_a| |y_b| (the two-half split), i.e. ~1e-5 of the diagonal scale.
+struct SdMfmaDev {
+    const int* tbase;             // [nb+1] first tile of each block
+    const int* tptr;              // [tiles+1] entry ranges
+    const unsigned short* trc;    // row in tile << 5 | column in tile
+    const int* tepos;             // CSR position
+};
+constexpr int SDM_GT = 4;   // union tiles per workgroup
+constexpr int SDM_KC = 2;   // k-steps per chunk (64 bytes per row and plane)
+template <int MT> constexpr int sdm_rows() { return 32 * MT + 32 * SDM_GT; }
+template <int MT> constexpr int sdm_chunk_bytes() { return 2 * sdm_rows<MT>() * 32 * SDM_KC; }
+template <int MT> constexpr int sdm_lds_bytes() { return sdm_rows<MT>() * 4 + 2 * sdm_chunk_bytes<MT>(); }
+
+template <int MT>
+__global__ __launch_bounds__(4 * MT * 64)
+void k_sddmm_mfma(MfmaDev M, SdMfmaDev S, int K, int Dpad, size_t plane_bytes, const char* __restrict__ Ypl, const float* __restrict__ d,
+                  const double* __restrict__ tr_part, int ntr, const int* __restrict__ diag_pos, float* __restrict__ xval) {
+    constexpr int NW = 4 * MT, THREADS = NW * 64;
+    constexpr int RA = 32 * MT, R = sdm_rows<MT>();
+    constexpr int CHUNK = sdm_chunk_bytes<MT>();
+    constexpr int NP = 2 * R / 16;  // 1-KiB pieces per chunk: 16 rows x 64 bytes
+    constexpr int NJ = (NP + NW - 1) / NW;
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    int* rows_l = reinterpret_cast<int*>(smem_raw);  // [R] global row ids: the block's rows, then this workgroup's union rows
+    char* bufs = smem_raw + R * 4;
+    const unsigned bufs_l = (unsigned)(size_t)(lds_vp)bufs;
+    __shared__ double sh_tr[NW];
+
+    const int per = (M.nb + 7) >> 3;
+    const int rb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (rb >= M.nb) return;
+    const int* dsc = M.desc + (size_t)rb * 8;
+    const int q0 = dsc[0], nrows = dsc[1], nun = dsc[5];
+    const int ntile = (nun + 31) >> 5;
+    const int ut0 = blockIdx.y * SDM_GT;  // first union tile of this workgroup
+    if (ut0 >= ntile) return;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wv >> 2, wn = wv & 3;
+
+    double tsum = 0.0;
+    for (int i = threadIdx.x; i < ntr; i += THREADS) tsum += tr_part[i];
+    tsum = wave_sum(tsum);
+    if (lane == 0) sh_tr[wv] = tsum;
+    for (int i = threadIdx.x; i < R; i += THREADS) {
+        int g;
+        if (i < RA) g = M.order[q0 + min(i, nrows - 1)];  // rows past the block's last repeat it; their outputs are never referenced
+        else g = M.un_fixed[(size_t)rb * MF_UNION_ROWS + min(ut0 * 32 + (i - RA), MF_UNION_ROWS - 1)];
+        rows_l[i] = g;
+    }
+    __syncthreads();
+    double tr = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tr += sh_tr[w];
+    tr /= (double)K;
+
+    // DMA pieces of this wave: piece i = wv + NW j covers plane i / (R / 16), rows 16 g .. 16 g + 15; lane L -> row 16 g + (L >> 2),
+    // position L & 3, which holds source slot (position - (row >> 2)) & 3 of the row's 64-byte chunk segment
+    const unsigned pitch = (unsigned)Dpad * 2u;
+    const char* pbase[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int i = wv + NW * j;
+        pbase[j] = Ypl;
+        if (i < NP) {
+            const int p = i / (R / 16), g = i - p * (R / 16);
+            const int row = 16 * g + (lane >> 2), pos = lane & 3;
+            const int slot = (pos - (row >> 2)) & 3;
+            pbase[j] = Ypl + ((size_t)p * plane_bytes + (size_t)(unsigned)rows_l[row] * pitch + (size_t)slot * 16u);
+        }
+    }
+    const int cw = wv < NP ? (NP - wv + NW - 1) / NW : 0;
+    auto issue = [&](int c) {
+        const unsigned dst_l = bufs_l + (unsigned)((c & 1) * CHUNK);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if (j < cw) mf_dma16(pbase[j] + (size_t)c * (32 * SDM_KC), dst_l + (unsigned)((wv + NW * j) * 1024));
+    };
+    // fragment addresses: lane (r = lane & 31, h = lane >> 5) reads row `ra` (A) / `rbw` (B), slot 2 kk + h, stored at
+    // position (slot + (row >> 2)) & 3
+    const int r = lane & 31, h = lane >> 5;
+    const int ra = 32 * wm + r, rbw = RA + 32 * wn + r;
+    unsigned offA[SDM_KC], offB[SDM_KC];
+#pragma unroll
+    for (int kk = 0; kk < SDM_KC; ++kk) {
+        offA[kk] = (unsigned)(ra * 64 + (((2 * kk + h) + (ra >> 2)) & 3) * 16);
+        offB[kk] = (unsigned)(rbw * 64 + (((2 * kk + h) + (rbw >> 2)) & 3) * 16);
+    }
+    constexpr unsigned PLANE_L = (unsigned)(R * 64);
+    mf_f16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+    const int NC = Dpad / (16 * SDM_KC);
+    issue(0);
+    for (int c = 0; c < NC; ++c) {
+        mf_wait_vmcnt(0);              // two buffers: chunk c is the only one outstanding here
+        __builtin_amdgcn_s_barrier();  // chunk c landed for everyone; everyone left the other buffer
+        if (c + 1 < NC) issue(c + 1);
+        const char* cb = bufs + (c & 1) * CHUNK;
+#pragma unroll
+        for (int kk = 0; kk < SDM_KC; ++kk) {
+            const uint4 ah = *reinterpret_cast<const uint4*>(cb + offA[kk]);
+            const uint4 al = *reinterpret_cast<const uint4*>(cb + PLANE_L + offA[kk]);
+            const uint4 bh = *reinterpret_cast<const uint4*>(cb + offB[kk]);
+            const uint4 bl = *reinterpret_cast<const uint4*>(cb + PLANE_L + offB[kk]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mf_bf8, al), __builtin_bit_cast(mf_bf8, bh), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mf_bf8, ah), __builtin_bit_cast(mf_bf8, bl), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mf_bf8, ah), __builtin_bit_cast(mf_bf8, bh), acc, 0, 0, 0);
+        }
+    }
+    __syncthreads();  // every wave is done with the chunk buffers: they now hold the 32 x 32 output tiles, one per wave
+    float* tile = reinterpret_cast<float*>(bufs) + wv * 1024;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) tile[((v & 3) + 8 * (v >> 2) + 4 * h) * 32 + r] = acc[v];  // C layout: column = lane & 31
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int ut = ut0 + wn;
+    if (ut < ntile) {
+        const int t = S.tbase[rb] + ut * MT + wm;
+        for (int w = S.tptr[t] + lane; w < S.tptr[t + 1]; w += 64) xval[S.tepos[w]] = (float)((double)tile[S.trc[w]] / tr);
+    }
+    if (blockIdx.y == 0)  // the diagonal of the block's rows from the exact row norms
+        for (int i = threadIdx.x; i < nrows; i += THREADS) {
+            const int row = rows_l[i];
+            xval[diag_pos[row]] = (float)((double)d[row] / tr);
+        }
+}
+
 }  // namespace mmw

@@ -74,6 +74,9 @@ template <typename T> struct Solver final : mmw_solver {
     bool lblk_stale = false;         // lval_blk lags lval (the matrix-core kernel ran the last products)
     DevBuf<int> b_kbase, b_fpos, b_mdesc, b_munfixed, b_morder;  // matrix-core SpMM: its row blocks, CSR entry -> fragment image position
     DevBuf<unsigned> afrag;          // the matrix as bf16 hi << 16 | lo words in MFMA fragment order
+    DevBuf<int> b_tbase, b_tptr, b_tepos;  // matrix-core SDDMM: pattern entries by 32 x 32 output tile
+    DevBuf<unsigned short> b_trc, xh_planes;
+    bool sddmm_mfma = false;
     size_t afrag_n = 0;
     int blocking_mode = 1;  // 1: use when profitable, 0: never
     // optimistic (no per-iteration readback) batches: snapshot for the rare replay
@@ -299,6 +302,11 @@ template <typename T> struct Solver final : mmw_solver {
             eng.mf.kbase = b_kbase.p;
             eng.mf.afrag = afrag.p;
             eng.mf_mt = HB.mfma_mt;
+            if (!getenv("MMW_NO_MFMA_SDDMM")) {
+                MMW_TRY(b_tbase.upload(HB.m_tbase, st)); MMW_TRY(b_tptr.upload(HB.m_tptr, st)); MMW_TRY(b_trc.upload(HB.m_trc, st));
+                MMW_TRY(b_tepos.upload(HB.m_tepos, st));
+                sddmm_mfma = true;
+            }
             if ((size_t)HB.nbm() > (size_t)MAX_PART && HB.nbm() > HB.nb()) {
                 MMW_TRY(eng.partial.alloc((size_t)HB.nbm() * eng.lay.Dpad));
                 MMW_TRY(eng.partial_o2.alloc((size_t)HB.nbm() * eng.lay.Dpad));
@@ -748,13 +756,42 @@ template <typename T> struct Solver final : mmw_solver {
             }
             MMW_TRY(kt.end());
             MMW_HIP(hipGetLastError());
+            // X on the pattern runs on the matrix cores too when the exponential did: the combination then also writes y's planes
+            const bool sd_mf = sddmm_mfma && eng.use_blk && eng.method == MMW_EXPM_LANCZOS && (Dpad % 32) == 0;
+            eng.out_planes = nullptr;
+            if constexpr (sizeof(T) == 4) {
+                if (sd_mf) {
+                    if (xh_planes.n < 2 * eng.bs) MMW_TRY(xh_planes.alloc(2 * eng.bs));
+                    eng.out_planes = xh_planes.p;
+                }
+            }
             eng.rownorm_d = drow.p;  // the Lanczos combination also emits the row norms and the trace slabs
             eng.rownorm_part = tr_part.p;
             MMW_TRY(eng.apply(Xh.p, 0.5, m_launch));
             MMW_TRY(kt.begin(KT_SDDMM));
             if (eng.method != MMW_EXPM_LANCZOS)
                 hipLaunchKernelGGL((k_rownorm2<T>), dim3(gr), dim3(BLOCK), 0, st, K, Dpad, Xh.p, drow.p, tr_part.p);
-            if (sddmm_blk2 && eng.use_blk) {
+            bool sd_done = false;
+            if constexpr (sizeof(T) == 4) {
+                if (sd_mf) {
+                    SdMfmaDev SM;
+                    SM.tbase = b_tbase.p; SM.tptr = b_tptr.p; SM.trc = b_trc.p; SM.tepos = b_tepos.p;
+                    const dim3 grid((HB.nbm() + 7) / 8 * 8, (HB.m_ntile_max + SDM_GT - 1) / SDM_GT);
+                    static bool attr1 = false, attr2 = false;
+                    if (HB.mfma_mt == 2) {
+                        if (!attr2) { MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sddmm_mfma<2>), hipFuncAttributeMaxDynamicSharedMemorySize, sdm_lds_bytes<2>())); attr2 = true; }
+                        hipLaunchKernelGGL((k_sddmm_mfma<2>), grid, dim3(512), sdm_lds_bytes<2>(), st, eng.mf, SM, K, Dpad, eng.bs * sizeof(unsigned short),
+                                           reinterpret_cast<const char*>(xh_planes.p), drow.p, tr_part.p, gr, d_diag.p, xval.p);
+                    } else {
+                        if (!attr1) { MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sddmm_mfma<1>), hipFuncAttributeMaxDynamicSharedMemorySize, sdm_lds_bytes<1>())); attr1 = true; }
+                        hipLaunchKernelGGL((k_sddmm_mfma<1>), grid, dim3(256), sdm_lds_bytes<1>(), st, eng.mf, SM, K, Dpad, eng.bs * sizeof(unsigned short),
+                                           reinterpret_cast<const char*>(xh_planes.p), drow.p, tr_part.p, gr, d_diag.p, xval.p);
+                    }
+                    sd_done = true;
+                }
+            }
+            if (sd_done) {
+            } else if (sddmm_blk2 && eng.use_blk) {
                 unsigned long long* sd_stamps = nullptr;  // MMW_SD_STAMPS=1: phase stamps of the last iteration's SDDMM
                 DevBuf<unsigned long long> stamp_buf;
                 if (it + 1 == n && getenv("MMW_SD_STAMPS")) {
