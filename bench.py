@@ -56,9 +56,12 @@ WORKLOADS = {
 }
 
 
-def make_state(kind, kw):
+def make_state(kind, kw, geometry=False):
     from sig_sdp_mmw_amd import graphs
-    return graphs.journal_graph(**kw) if kind == "journal" else graphs.er_contention_graph(**kw)
+    if kind == "journal":
+        return graphs.journal_graph(return_geometry=True, **kw) if geometry else graphs.journal_graph(**kw)
+    st = graphs.er_contention_graph(**kw)
+    return (st, None) if geometry else st
 
 
 def first_midpoint(state):
@@ -132,7 +135,7 @@ def spawn_ranks(n, cmd, env=None, timeout=None):
     return rc, out0
 
 
-def coloring_block(state, dtype_name, nit, eta, warm):
+def coloring_block(state, dtype_name, nit, eta, warm, geometry=None):
     """Wall-clock of the whole binary search (binary_search_relaxation.run) to a feasible colouring, with the device-RNG /
     batched-rounding fast path of the drop-in class (the flow of sim_script/journal_version/sim_mmw_time.py:30-36)."""
     from sig_sdp_mmw_amd.binary_search import binary_search_relaxation
@@ -149,7 +152,17 @@ def coloring_block(state, dtype_name, nit, eta, warm):
     lg = alg.LOGGED_NP_DATA
     alg.close()
     ms = lambda us: round(float(us) / 1e3, 2)
-    return {"wall_s": round(wall, 4), "Z": int(Z), "rem": int(rem), "probes": int(per.shape[0]), "nit_per_probe": int(nit),
+    score = None
+    if geometry is not None:  # what every reference driver prints after the colouring (pd_mmw_template.py:31-33): BLER on the device scorer
+        from sig_sdp_mmw_amd import _lib
+        from sig_sdp_mmw_amd.graphs import min_sinr_dec, _NOISE_FLOOR_DBM
+        env = _lib.DeviceEnv(geometry["sta_locs"], geometry["ap_locs"], min_sinr=min_sinr_dec(), noise_floor_dbm=_NOISE_FLOOR_DBM)
+        s0 = time.perf_counter()
+        sinr, bler = env.evaluate(z_vec, int(Z))
+        score = {"bler_mean": float(np.mean(bler)), "bler_max": float(np.max(bler)), "sinr_min": float(np.min(sinr)),
+                 "scorer_ms": round((time.perf_counter() - s0) * 1e3, 2)}
+        env.close()
+    return {"wall_s": round(wall, 4), "Z": int(Z), "rem": int(rem), "probes": int(per.shape[0]), "nit_per_probe": int(nit), "score": score,
             "warm_start": bool(warm), "mids": [int(x) for x in per[:, 5]], "rems": [int(x) for x in per[:, 7]],
             "iterations": [int(x) for x in lg["mmw_iters"][:, 5]] if "mmw_iters" in lg else None,
             "per_probe_ms": {"solve": [ms(x) for x in per[:, 8]], "rounding": [ms(x) for x in per[:, 9]],
@@ -214,7 +227,9 @@ def main():
     w = 4 if dtype_name == "f32" else 8
     n_inst = world * M
     mine = sharding.instances_of_rank(n_inst, rank, world)  # instance i -> rank i % world; its seed is its id
-    states = [make_state(*factory(i)) for i in mine]
+    made = [make_state(*factory(i), geometry=True) for i in mine]
+    states = [m[0] for m in made]
+    geometry0 = made[0][1]
     Zs = [Zfix if Zfix is not None else first_midpoint(st) for st in states]
     nit = args.warmup + args.steps
     method = _lib.EXPM_LANCZOS if args.expm == "lanczos" else _lib.EXPM_TAYLOR
@@ -314,7 +329,7 @@ def main():
     if rank == 0 and world == 1 and M == 1 and not args.no_coloring:
         for s in solvers[1:]:
             s.close()
-        out["coloring"] = coloring_block(state, dtype_name, args.coloring_nit, args.eta, warm=not args.coloring_cold)
+        out["coloring"] = coloring_block(state, dtype_name, args.coloring_nit, args.eta, warm=not args.coloring_cold, geometry=geometry0)
 
     # ---- CPU baseline: the oracle on this host, bounded sample of the same instance (rank 0, N = 1 only)
     if rank == 0 and world == 1 and args.cpu_iters != 0:

@@ -257,6 +257,8 @@ def test_matrix_core_spmm_matches_the_fp32_kernel_and_the_oracle(Z, monkeypatch)
     assert b.read(_lib.F_SPMM_KIND)[0] in (1.0, 2.0)
     b.iterate(nit, sk)
     assert relerr(xa, b.read(_lib.F_XHALF)) < 2e-6        # same result as the fp32 LDS kernel to fp32 rounding
+    assert relerr(a.read(_lib.F_XVAL), b.read(_lib.F_XVAL)) < 3e-5   # X on the pattern: matrix-core SDDMM (two-half split) vs fp32 SDDMM
+    assert np.array_equal(np.isfinite(a.read(_lib.F_XVAL)), np.ones(a.nnzL, dtype=bool))
     a.close(); b.close()
 
 

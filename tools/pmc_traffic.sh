@@ -8,7 +8,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic
 rm -rf $OUT; mkdir -p $OUT
 export MMW_SYNC_PLAN=1   # exact launches only: no early-exited stages in the per-kernel means
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --cpu-iters 0 > $OUT/$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --cpu-iters 0 --no-coloring > $OUT/$c.log 2>&1
 done
 python3 - <<PY
 import csv, glob, json, collections
@@ -20,16 +20,16 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             k = r["Kernel_Name"].split("(")[0]
             acc[k][c][0] += 1; acc[k][c][1] += float(r["Counter_Value"])
 allk = {k: {c: {"launches": v[0], "mean_KB": round(v[1] / v[0], 1)} for c, v in d.items()} for k, d in acc.items()}
-key = [k for k in allk if "k_spmm_blk2<float, 1>" in k or "k_spmm_blk2<float, (int)1>" in k]
+key = [k for k in allk if "k_spmm_mfma<1" in k or "k_spmm_mfma<(int)1" in k] or [k for k in allk if "k_spmm_blk2<float, 1>" in k or "k_spmm_blk2<float, (int)1>" in k]
 rec = {"workload": "journal-1pct",
-       "command": "MMW_SYNC_PLAN=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py --steps 50 --warmup 5 --cpu-iters 0",
+       "command": "MMW_SYNC_PLAN=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py --steps 50 --warmup 5 --cpu-iters 0 --no-coloring",
        "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE reads 1/2 of a wide (16 B/lane) coalesced read stream -> x2; WRITE_SIZE exact; unit KB -> x1024",
-       "note": "exact launches (plan read back every iteration); the whole working set (~75 MB) is resident in the 256 MiB Infinity Cache, whose hits these fabric-side counters include",
+       "note": "exact launches (plan read back every iteration); the whole working set (~110 MB) is resident in the 256 MiB Infinity Cache, whose hits these fabric-side counters include",
        "all_kernels_KB": allk}
 if key:
     k = key[0]
     f, w = allk[k]["FETCH_SIZE"], allk[k]["WRITE_SIZE"]
-    rec.update({"kernel": "k_spmm_blk2<float, SPMM_LANCZOS>", "FETCH_SIZE_KB_mean": f["mean_KB"], "WRITE_SIZE_KB_mean": w["mean_KB"],
+    rec.update({"kernel": k.split("(")[0] + " (Lanczos epilogue)", "FETCH_SIZE_KB_mean": f["mean_KB"], "WRITE_SIZE_KB_mean": w["mean_KB"],
                 "launches": f["launches"], "traffic_bytes_per_launch": int((2 * f["mean_KB"] + w["mean_KB"]) * 1024)})
 json.dump(rec, open("$GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_traffic_journal-1pct.json", "w"), indent=1)
 print({k: rec.get(k) for k in ("kernel", "FETCH_SIZE_KB_mean", "WRITE_SIZE_KB_mean", "launches", "traffic_bytes_per_launch")})
