@@ -258,6 +258,8 @@ template <typename T> struct ExpmEngine {
         MMW_TRY(scal.alloc((size_t)4 * (MAX_ORDER + 2) * lay.Dpad));
         MMW_TRY(row_part.alloc((size_t)3 * ROW_GRID_MAX));
         MMW_TRY(plan_d.alloc(1));
+        MMW_HIP(hipMemsetAsync(plan_d.p, 0, sizeof(ExpmPlan), st));
+        MMW_TRY(reset_plan_history(false));
         MMW_TRY(viol_d.alloc(1));
         MMW_HIP(hipMemsetAsync(viol_d.p, 0, sizeof(int), st));
         if (!plan_h) MMW_HIP(hipHostMalloc((void**)&plan_h, sizeof(ExpmPlan)));
@@ -366,9 +368,16 @@ template <typename T> struct ExpmEngine {
     // m_launch == 0: read the plan back (one stream sync) and launch exactly what it asks for;
     // m_launch  > 0: no readback -- the caller launches m_launch single-substep stages and the kernels
     //                themselves skip the stages beyond the device-side order (viol is raised if it needs more).
+    int plan_iter = 0;  // iteration index of the matrix `val` currently holds (the owner keeps it; stand-alone uses stay at 0)
+    int reset_plan_history(bool keep_sums) {
+        hipLaunchKernelGGL(k_plan_reset, dim3(1), dim3(64), 0, st, plan_d.p, keep_sums ? 1 : 0);
+        MMW_HIP(hipGetLastError());
+        return MMW_OK;
+    }
     int make_plan(double ascale, int m_launch) {
         hipLaunchKernelGGL((k_rowsums<T>), dim3(nwide), dim3(BLOCK), 0, st, K, indptr, col, val, ascale, row_part.p);
-        hipLaunchKernelGGL(k_plan, dim3(1), dim3(PLAN_THREADS), 0, st, K, method, max_order, tol, row_part.p, nwide, plan_d.p, m_launch, viol_d.p, apost() ? 1 : 0);
+        hipLaunchKernelGGL(k_plan, dim3(1), dim3(PLAN_THREADS), 0, st, K, method, max_order, tol, row_part.p, nwide, plan_d.p, m_launch, viol_d.p, apost() ? 1 : 0,
+                           plan_iter);
         MMW_HIP(hipGetLastError());
         if (m_launch > 0) return MMW_OK;
         MMW_HIP(hipMemcpyAsync(plan_h, plan_d.p, sizeof(ExpmPlan), hipMemcpyDeviceToHost, st));
@@ -401,8 +410,9 @@ template <typename T> struct ExpmEngine {
     }
 
     // out = exp(ascale*A) * start_block().  `out` must not alias the engine's blocks.
-    int apply(T* out, double ascale, int m_launch = 0) {
-        MMW_TRY(make_plan(ascale, m_launch));
+    // plan_made: the caller's own kernels already left this application's (lagged) plan in plan_d
+    int apply(T* out, double ascale, int m_launch = 0, bool plan_made = false) {
+        if (!plan_made) MMW_TRY(make_plan(ascale, m_launch));
         const int m = m_launch > 0 ? m_launch : last.m;
         const int nsub = m_launch > 0 ? 1 : last.nsub;
         MMW_TRY(ensure_blocks(std::max(3, m)));

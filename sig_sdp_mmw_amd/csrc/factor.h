@@ -280,16 +280,24 @@ template <typename T> struct Factorizer {
         bool done = false;
         double prev_resid = -1.0;
         int degree = 12;  // filter degree schedule 12, 30, 40, 40, ...: few Rayleigh-Ritz / orthonormalisation rounds
+        int rr_skip = 0;  // filter passes still to run before the next Rayleigh-Ritz
+        bool skip_rr = false;
         for (; outer < max_outer && !done; ++outer) {
             // ---- Rayleigh-Ritz on span(V)
             MMW_TRY((spmm<SPMM_PLAIN>(lay, nblk, indptr, col, val, V.p, W.p, nullptr, nullptr, ascale, 0.0, 0.0)));
+            // The Rayleigh-Ritz step (Gram matrix, dense eigensolve, two tall GEMMs, residuals) only rotates the basis and tells how
+            // far it is: the filter works on the subspace whatever its basis.  While the last residual says that more than one
+            // more filter pass is needed anyway, passes run back to back on the Ritz values of the last Rayleigh-Ritz.
+            const bool no_rr = rr_skip > 0 && b < K;
+            if (no_rr) --rr_skip;
+            else {
             MMW_TRY(dw.gram(K, b, ld, V.p, W.p, true));
             // A random start block spans nothing of interest yet: its Rayleigh quotients (the diagonal of G) are all the first
             // filter needs, and the dense eigensolve of a random projection is the most expensive one of the run (b > 96: ~10
             // Jacobi sweeps of b - 1 launches each).
             // (Seeding the block with the previous probe's Ritz vectors was tried: the averaged X of neighbouring slot counts
             // do not share their leading subspace -- first residual 0.2 either way -- so every call starts from a random block.)
-            const bool skip_rr = outer == 0 && b > JAC_LDS_MAX && b < K && !getenv("MMW_FACTOR_FULL_RR");
+            skip_rr = outer == 0 && b > JAC_LDS_MAX && b < K && !getenv("MMW_FACTOR_FULL_RR");
             if (skip_rr) {
                 hipLaunchKernelGGL(k_set_eye, dim3(grid_elems((size_t)b * b)), dim3(BLOCK), 0, st, b, dw.Q.p);
                 hipLaunchKernelGGL(k_get_diag, dim3(grid_elems(b)), dim3(BLOCK), 0, st, b, dw.G.p, dw.diag.p);
@@ -330,6 +338,8 @@ template <typename T> struct Factorizer {
                 done = true;
                 break;
             }
+            if (!skip_rr && !getenv("MMW_FACTOR_FULL_RR")) rr_skip = last_resid > 1e3 * tol ? 2 : (last_resid > 30.0 * tol ? 1 : 0);
+            }  // Rayleigh-Ritz
             // ---- Chebyshev filter on B = A^2 damping [0, cut], cut = smallest Ritz value of B in the block
             const double mu_top = theta[0] * theta[0];
             double cut = theta[b - 1] * theta[b - 1];
@@ -364,9 +374,12 @@ template <typename T> struct Factorizer {
             }
             MMW_TRY(orthonormalise(b, ld, V, W, 1e-14));
             // adaptive degree: grow while the residual keeps falling, back off when rounding stalls the filter
-            if (prev_resid > 0.0 && last_resid > 0.5 * prev_resid) degree = std::max(4, degree / 2);
-            else degree = degree < 30 ? 30 : 40;
-            prev_resid = last_resid;
+            if (no_rr) degree = degree < 30 ? 30 : 40;  // no new residual: keep following the schedule
+            else {
+                if (prev_resid > 0.0 && last_resid > 0.5 * prev_resid) degree = std::max(4, degree / 2);
+                else degree = degree < 30 ? 30 : 40;
+                prev_resid = last_resid;
+            }
         }
         outer_done = outer;
         if (kt) MMW_TRY(kt->end());

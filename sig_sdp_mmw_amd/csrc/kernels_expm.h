@@ -30,6 +30,13 @@ struct ExpmPlan {      // written by k_plan, read by every expm kernel
     int m_eff;         // steps the last application actually used (written by the combination)
     int mfma_ok;       // 1: the two-half bf16 split of the matrix-core SpMM (kernels_mfma.h) keeps the product within tol
     double absn;       // max_i sum_j |a_ij| of the scaled matrix (the bound behind mfma_ok)
+    // Lagged planning (the loop's optimistic chunks): the row sums of the matrix are made one iteration late, inside the DUAL
+    // pass that reads the same rows, and the bounds for the matrix that is multiplied are extrapolated from the last two
+    // matrices seen; the next plan checks that the extrapolation covered it (else *viol: the chunk is replayed with exact plans).
+    int lagged;        // 1: rho / absn / mu above are extrapolated bounds, to be verified by the next plan
+    int h_iter;        // iteration index of the last matrix whose sums were seen (-1: none, sums of the zero matrix)
+    double h_pp, h_pm, h_mu;  // its sums: max_i (d_i + o_i), max_i (o_i - d_i), trace / K
+    double g_pp, g_pm, g_mu;  // growth per iteration of those sums (last finite difference)
     unsigned conv[MAX_ORDER + 2];  // conv[j]: float bits of the largest per-column estimate after j steps (valid once step j's scalars ran)
 };
 // Steps that run, given the estimates of the steps <= upto that have completed.  The a-priori order is a bound from the
@@ -1323,10 +1330,12 @@ __host__ __device__ inline int plan_order(int method, double rho, double tol, in
 
 // m_launch > 0: the host has already decided to launch m_launch steps with a single substep (no readback);
 // if the matrix needs more, the sticky flag *viol is raised and the caller replays the batch synchronously.
+// iter_seen: iteration index of the matrix the sums in `part` were taken from; lagged != 0: that matrix is one iteration older
+// than the one about to be multiplied (see ExpmPlan).
 constexpr int PLAN_THREADS = 256;
-__global__ __launch_bounds__(PLAN_THREADS) void k_plan(int K, int method, int max_order, double tol, const double* __restrict__ part, int np,
-                                                       ExpmPlan* __restrict__ plan, int m_launch, int* __restrict__ viol, int apost) {
-    __shared__ double sh[PLAN_THREADS / WAVE];
+__device__ __forceinline__ void plan_body(int K, int method, int max_order, double tol, const double* __restrict__ part, int np,
+                                          ExpmPlan* __restrict__ plan, int m_launch, int* __restrict__ viol, int apost, int iter_seen, int lagged,
+                                          double* sh /* [PLAN_THREADS / WAVE] */) {
     double tr = 0.0, pp = -1e300, pm = -1e300;
     for (int i = threadIdx.x; i < np; i += PLAN_THREADS) {
         tr += part[i];
@@ -1336,10 +1345,38 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan(int K, int method, int ma
     tr = block_sum(tr, sh);
     pp = block_max(pp, sh);
     pm = block_max(pm, sh);
-    const double mu = tr / K;
-    const double r = pp - mu > pm + mu ? pp - mu : pm + mu;
+    double mu = tr / K;
     if (threadIdx.x == 0) {
         ExpmPlan p;
+        const ExpmPlan old = *plan;
+        // the previous plan's extrapolated bounds against the sums of the matrix it was used on (seen only now)
+        if (old.lagged && iter_seen == old.h_iter + 1) {
+            const double need = pp - old.mu > pm + old.mu ? pp - old.mu : pm + old.mu;
+            const double absn_seen = pp > pm ? pp : pm;
+            if (need > old.rho || (old.mfma_ok && 2.3e-5 * absn_seen > old.tol)) *viol = 1;
+        }
+        // history and growth per iteration
+        p.h_iter = old.h_iter; p.h_pp = old.h_pp; p.h_pm = old.h_pm; p.h_mu = old.h_mu;
+        p.g_pp = old.g_pp; p.g_pm = old.g_pm; p.g_mu = old.g_mu;
+        if (iter_seen > old.h_iter) {
+            const double dt = (double)(iter_seen - old.h_iter);
+            p.g_pp = (pp - old.h_pp) / dt; p.g_pm = (pm - old.h_pm) / dt; p.g_mu = (mu - old.h_mu) / dt;
+            p.h_iter = iter_seen; p.h_pp = pp; p.h_pm = pm; p.h_mu = mu;
+        }
+        p.lagged = lagged;
+        if (lagged) {
+            // Bounds for the next matrix: one more step of growth, with a factor 2.  The matrix is a running sum of bounded
+            // increments, so its sums grow by about 1 / (iterations so far) of themselves per step: that average rate backs the
+            // last finite difference (which is noisy: the maxima move between rows).
+            const double avg = 1.0 / (double)(iter_seen + 2);
+            const double spread = (fabs(pp) > fabs(pm) ? fabs(pp) : fabs(pm)) + fabs(mu);
+            const double gp = p.g_pp > avg * spread ? p.g_pp : avg * spread, gm = p.g_pm > avg * spread ? p.g_pm : avg * spread;
+            const double mu1 = mu + p.g_mu;
+            pp += 2.0 * gp + 1e-3 * spread;
+            pm += 2.0 * gm + 1e-3 * spread;
+            mu = mu1;
+        }
+        const double r = pp - mu > pm + mu ? pp - mu : pm + mu;
         p.rho = r;
         p.mu = mu;
         p.tol = tol;
@@ -1371,6 +1408,51 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan(int K, int method, int ma
             p.m = m < m_launch ? m : m_launch;  // keep the launched kernels in range
             p.nsub = 1;
         }
+        *plan = p;
+    }
+}
+__global__ __launch_bounds__(PLAN_THREADS) void k_plan(int K, int method, int max_order, double tol, const double* __restrict__ part, int np,
+                                                       ExpmPlan* __restrict__ plan, int m_launch, int* __restrict__ viol, int apost, int iter_seen) {
+    __shared__ double sh[PLAN_THREADS / WAVE];
+    plan_body(K, method, max_order, tol, part, np, plan, m_launch, viol, apost, iter_seen, 0, sh);
+}
+// End of a chunk: the last iteration's extrapolated bounds against the sums of the matrix they were used on (part = k_rowsums of
+// it), since no later plan of the chunk will see that matrix; also brings the history up to it.
+__global__ __launch_bounds__(PLAN_THREADS) void k_plan_verify(int K, const double* __restrict__ part, int np, ExpmPlan* __restrict__ plan,
+                                                              int* __restrict__ viol, int iter_seen) {
+    __shared__ double sh[PLAN_THREADS / WAVE];
+    double tr = 0.0, pp = -1e300, pm = -1e300;
+    for (int i = threadIdx.x; i < np; i += PLAN_THREADS) {
+        tr += part[i];
+        pp = part[np + i] > pp ? part[np + i] : pp;
+        pm = part[2 * np + i] > pm ? part[2 * np + i] : pm;
+    }
+    tr = block_sum(tr, sh);
+    pp = block_max(pp, sh);
+    pm = block_max(pm, sh);
+    if (threadIdx.x == 0) {
+        ExpmPlan p = *plan;
+        const double mu = tr / K;
+        if (p.lagged && iter_seen == p.h_iter + 1) {
+            const double need = pp - p.mu > pm + p.mu ? pp - p.mu : pm + p.mu;
+            if (need > p.rho || (p.mfma_ok && 2.3e-5 * (pp > pm ? pp : pm) > p.tol)) *viol = 1;
+        }
+        if (iter_seen > p.h_iter) {
+            const double dt = (double)(iter_seen - p.h_iter);
+            p.g_pp = (pp - p.h_pp) / dt; p.g_pm = (pm - p.h_pm) / dt; p.g_mu = (mu - p.h_mu) / dt;
+            p.h_iter = iter_seen; p.h_pp = pp; p.h_pm = pm; p.h_mu = mu;
+        }
+        p.lagged = 0;
+        *plan = p;
+    }
+}
+// history of a fresh run: the zero matrix at iteration -1 (keep_sums: a warm restart keeps the sums of the matrix it continues from)
+__global__ void k_plan_reset(ExpmPlan* __restrict__ plan, int keep_sums) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        ExpmPlan p = *plan;
+        p.lagged = 0;
+        p.h_iter = -1;
+        if (!keep_sums) { p.h_pp = p.h_pm = p.h_mu = 0.0; p.g_pp = p.g_pm = p.g_mu = 0.0; }
         *plan = p;
     }
 }

@@ -72,19 +72,37 @@ __global__ __launch_bounds__(BLOCK) void k_dual_rows(PatternDev<T> P, const T* _
 // ---- DUAL, step 2: eH = (S_T' r (Z-1)/Z - (h - S_sum/Z)) / norm_H ; e_accu += eta e ; block max ----
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_dual_h(PatternDev<T> P, const T* __restrict__ rsum, T* __restrict__ e_this,
-                                                  T* __restrict__ e_accu, double eta, double* __restrict__ max_part) {
+                                                  T* __restrict__ e_accu, double eta, double* __restrict__ max_part,
+                                                  const T* __restrict__ lval = nullptr, double lscale = 0.0,
+                                                  double* __restrict__ lpart = nullptr /* [3][grid], as k_rowsums */) {
     __shared__ double sh[WAVES_PER_BLOCK];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int K = P.K, Z = P.Z;
     double best = -1e300;
+    double sd = 0.0, pp = -1e300, pm = -1e300;  // sums of L for the (lagged) plan of the exponential, when lval is given
     const int baseH = K + P.E_asso;
     for (int row = blockIdx.x * WAVES_PER_BLOCK + wib; row < K; row += gridDim.x * WAVES_PER_BLOCK) {
-        double s = 0.0;
+        double s = 0.0, la = 0.0, ld = 0.0;
         for (int e = P.indptr[row] + lane; e < P.indptr[row + 1]; e += WAVE) {
             const double w = (double)P.sab[e];
-            if (w != 0.0) s += w * (double)rsum[P.col[e]];
+            const int c = P.col[e];
+            if (w != 0.0) s += w * (double)rsum[c];
+            if (lval) {  // the pass reads these rows anyway: |L| row sums and the diagonal, like k_rowsums
+                const double v = lscale * (double)lval[e];
+                if (c == row) ld = v;
+                else la += fabs(v);
+            }
         }
         s = wave_sum(s);
+        if (lval) {
+            la = wave_sum(la);
+            ld = wave_sum(ld);  // exactly one lane holds the diagonal
+            if (lane == 0) {
+                sd += ld;
+                pp = ld + la > pp ? ld + la : pp;
+                pm = la - ld > pm ? la - ld : pm;
+            }
+        }
         if (lane == 0) {
             const double eh = (s * (double)(Z - 1) / (double)Z - ((double)P.h_max[row] - (1.0 / (double)Z) * (double)P.S_sum[row])) *
                               (double)P.inv_norm_H[row];  // mmw.py:134
@@ -101,6 +119,16 @@ __global__ __launch_bounds__(BLOCK) void k_dual_h(PatternDev<T> P, const T* __re
     }
     best = block_max(best, sh);
     if (threadIdx.x == 0) max_part[blockIdx.x] = best;
+    if (lval) {
+        sd = block_sum(sd, sh);
+        pp = block_max(pp, sh);
+        pm = block_max(pm, sh);
+        if (threadIdx.x == 0) {
+            lpart[blockIdx.x] = sd;
+            lpart[gridDim.x + blockIdx.x] = pp;
+            lpart[2 * gridDim.x + blockIdx.x] = pm;
+        }
+    }
 }
 
 // ---- softmax pass A: Y <- exp(e_accu - max); per block sums {all, D block, F block, sum_H cH*Y/norm_H}
@@ -135,13 +163,26 @@ __global__ __launch_bounds__(BLOCK) void k_softmax_a(PatternDev<T> P, const T* _
         sum_part[3 * gridDim.x + blockIdx.x] = sW;
     }
 }
+struct PlanArgs {  // arguments of plan_body, for the workgroup that k_softmax_b lends to the planning
+    ExpmPlan* plan = nullptr;
+    const double* part = nullptr;
+    int* viol = nullptr;
+    double tol = 0.0;
+    int K = 0, method = 0, max_order = 0, np = 0, m_launch = 0, apost = 0, iter_seen = 0;
+};
 // ---- softmax pass B: Y /= total; yavg += Y; scalars for the loss {sumYD, sumYF, sum cH YH/normH}
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_softmax_b(int C, T* __restrict__ Y, T* __restrict__ yavg, int accumulate,
                                                      const double* __restrict__ sum_part, int npart,
                                                      double* __restrict__ scal /* [4] */, int baseH, const T* __restrict__ inv_norm_H,
-                                                     T* __restrict__ wH /* [K]: Y_H / norm_H, the weight the LOSS gathers */) {
+                                                     T* __restrict__ wH /* [K]: Y_H / norm_H, the weight the LOSS gathers */,
+                                                     PlanArgs pa = PlanArgs{}) {
     __shared__ double sh[WAVES_PER_BLOCK];
+    if (pa.plan && blockIdx.x == gridDim.x - 1) {
+        // one extra workgroup makes the exponential's plan from the row sums k_dual_h left two launches ago (lagged planning)
+        plan_body(pa.K, pa.method, pa.max_order, pa.tol, pa.part, pa.np, pa.plan, pa.m_launch, pa.viol, pa.apost, pa.iter_seen, 1, sh);
+        return;
+    }
     double s[4];
     for (int q = 0; q < 4; ++q) {
         double t = 0.0;
@@ -149,7 +190,8 @@ __global__ __launch_bounds__(BLOCK) void k_softmax_b(int C, T* __restrict__ Y, T
         s[q] = block_sum(t, sh);
     }
     const double total = s[0] + s[1] + s[2];
-    for (int c = blockIdx.x * BLOCK + threadIdx.x; c < C; c += gridDim.x * BLOCK) {
+    const int nwork = (int)gridDim.x - (pa.plan ? 1 : 0);  // the last workgroup went planning
+    for (int c = blockIdx.x * BLOCK + threadIdx.x; c < C; c += nwork * BLOCK) {
         const T y = (T)((double)Y[c] / total);
         Y[c] = y;
         if (accumulate) yavg[c] += y;

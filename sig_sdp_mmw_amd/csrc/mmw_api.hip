@@ -72,6 +72,8 @@ template <typename T> struct Solver final : mmw_solver {
     int sketch_done_slabs = 0;
     DevBuf<T> lval_blk;
     bool lblk_stale = false;         // lval_blk lags lval (the matrix-core kernel ran the last products)
+    bool lagged_plan = getenv("MMW_NO_LAGGED_PLAN") == nullptr;
+    DevBuf<ExpmPlan> sn_plan;        // plan (with its history) at the start of the pending chunk
     DevBuf<int> b_kbase, b_fpos, b_mdesc, b_munfixed, b_morder;  // matrix-core SpMM: its row blocks, CSR entry -> fragment image position
     DevBuf<unsigned> afrag;          // the matrix as bf16 hi << 16 | lo words in MFMA fragment order
     DevBuf<int> b_tbase, b_tptr, b_tepos;  // matrix-core SDDMM: pattern entries by 32 x 32 output tile
@@ -542,6 +544,7 @@ template <typename T> struct Solver final : mmw_solver {
         iter = 0;
         pending = false;
         if (eng.viol_d.p) MMW_TRY(eng.clear_violation());
+        MMW_TRY(eng.reset_plan_history(true));
         const size_t nnz = (size_t)H.nnzL(), C = (size_t)H.C();
         MMW_HIP(hipMemcpyAsync(xavg.p, xval.p, nnz * sizeof(T), hipMemcpyDeviceToDevice, st));
         MMW_HIP(hipMemcpyAsync(yavg.p, Y.p, C * sizeof(T), hipMemcpyDeviceToDevice, st));
@@ -557,6 +560,7 @@ template <typename T> struct Solver final : mmw_solver {
         pending = false;
         m_guess = 3;
         if (eng.viol_d.p) MMW_TRY(eng.clear_violation());
+        MMW_TRY(eng.reset_plan_history(false));
         const size_t nnz = (size_t)H.nnzL(), C = (size_t)H.C();
         MMW_HIP(hipMemsetAsync(lval.p, 0, nnz * sizeof(T), st));
         if (lval_blk.p) MMW_HIP(hipMemsetAsync(lval_blk.p, 0, (size_t)HB.nent * sizeof(T), st));
@@ -611,6 +615,8 @@ template <typename T> struct Solver final : mmw_solver {
         };
         MMW_TRY(cp(sn_lval, lval, nnz)); MMW_TRY(cp(sn_xval, xval, nnz));
         MMW_TRY(cp(sn_xavg, xavg, nnz)); MMW_TRY(cp(sn_Y, Y, C)); MMW_TRY(cp(sn_yavg, yavg, C)); MMW_TRY(cp(sn_eaccu, e_accu, C));
+        if (sn_plan.n < 1) MMW_TRY(sn_plan.alloc(1));
+        MMW_HIP(hipMemcpyAsync(save ? sn_plan.p : eng.plan_d.p, save ? eng.plan_d.p : sn_plan.p, sizeof(ExpmPlan), hipMemcpyDeviceToDevice, st));
         if (!save && lval_blk.p) lblk_stale = true;  // rebuilt from the restored values when the fp32 kernel next needs it
         if (!save && afrag.p) {  // the fragment image follows the restored values
             hipLaunchKernelGGL((k_refrag<T>), dim3(grid_elems(nnz)), dim3(BLOCK), 0, st, nnz, lval.p, b_fpos.p, afrag.p);
@@ -708,9 +714,20 @@ template <typename T> struct Solver final : mmw_solver {
             // ---- DUAL
             MMW_TRY(kt.begin(KT_DUAL));
             hipLaunchKernelGGL((k_dual_rows<T>), dim3(gr), dim3(BLOCK), 0, st, P, xval.p, rsum.p, e_this.p);
-            hipLaunchKernelGGL((k_dual_h<T>), dim3(gr), dim3(BLOCK), 0, st, P, rsum.p, e_this.p, e_accu.p, eta, max_part.p);
+            // Lagged planning inside a chunk (not its first iteration, which plans exactly): k_dual_h also takes the row sums of the
+            // L it walks over anyway -- last iteration's -- and one extra workgroup of k_softmax_b turns them into this iteration's plan
+            // (extrapolated bounds, checked by the next plan): k_rowsums + k_plan leave the critical path.
+            const bool lagged_it = optimistic && it > 0 && eng.method == MMW_EXPM_LANCZOS && lagged_plan;
+            PlanArgs pa;
+            if (lagged_it) {
+                pa.plan = eng.plan_d.p; pa.part = eng.row_part.p; pa.viol = eng.viol_d.p; pa.tol = eng.tol; pa.K = K; pa.method = eng.method;
+                pa.max_order = eng.max_order; pa.np = gr; pa.m_launch = m_launch; pa.apost = eng.apost() ? 1 : 0; pa.iter_seen = iter - 1;
+            }
+            hipLaunchKernelGGL((k_dual_h<T>), dim3(gr), dim3(BLOCK), 0, st, P, rsum.p, e_this.p, e_accu.p, eta, max_part.p,
+                               (const T*)(lagged_it ? lval.p : nullptr), 0.5, eng.row_part.p);
             hipLaunchKernelGGL((k_softmax_a<T>), dim3(gc), dim3(BLOCK), 0, st, P, e_accu.p, Y.p, max_part.p, gr, sum_part.p);
-            hipLaunchKernelGGL((k_softmax_b<T>), dim3(gc), dim3(BLOCK), 0, st, C, Y.p, yavg.p, acc, sum_part.p, gc, scal.p, K + (int)H.E_asso(), d_invn.p, wH.p);
+            hipLaunchKernelGGL((k_softmax_b<T>), dim3(gc + (lagged_it ? 1 : 0)), dim3(BLOCK), 0, st, C, Y.p, yavg.p, acc, sum_part.p, gc, scal.p,
+                               K + (int)H.E_asso(), d_invn.p, wH.p, pa);
             MMW_TRY(kt.end());
             MMW_TRY(record(1));
             // ---- LOSS
@@ -767,7 +784,8 @@ template <typename T> struct Solver final : mmw_solver {
             }
             eng.rownorm_d = drow.p;  // the Lanczos combination also emits the row norms and the trace slabs
             eng.rownorm_part = tr_part.p;
-            MMW_TRY(eng.apply(Xh.p, 0.5, m_launch));
+            eng.plan_iter = iter;
+            MMW_TRY(eng.apply(Xh.p, 0.5, m_launch, lagged_it));
             MMW_TRY(kt.begin(KT_SDDMM));
             if (eng.method != MMW_EXPM_LANCZOS)
                 hipLaunchKernelGGL((k_rownorm2<T>), dim3(gr), dim3(BLOCK), 0, st, K, Dpad, Xh.p, drow.p, tr_part.p);
@@ -844,6 +862,12 @@ template <typename T> struct Solver final : mmw_solver {
             MMW_HIP(hipGetLastError());
             MMW_TRY(record(3));
             ++iter;
+        }
+        if (optimistic && n > 1 && lagged_plan && eng.method == MMW_EXPM_LANCZOS) {
+            // the chunk's last plan was extrapolated and no later plan of the chunk sees its matrix: check it here
+            hipLaunchKernelGGL((k_rowsums<T>), dim3(eng.nwide), dim3(BLOCK), 0, st, K, d_indptr.p, d_col.p, lval.p, 0.5, eng.row_part.p);
+            hipLaunchKernelGGL(k_plan_verify, dim3(1), dim3(PLAN_THREADS), 0, st, K, eng.row_part.p, eng.nwide, eng.plan_d.p, eng.viol_d.p, iter - 1);
+            MMW_HIP(hipGetLastError());
         }
         return MMW_OK;
     }

@@ -38,3 +38,4 @@ for k, d in acc.items():
 json.dump(rec, open("$GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_mfma_journal-1pct.json", "w"), indent=1)
 for k, e in rec["kernels"].items(): print(k[:60], e)
 PY
+rm -rf $OUT  # raw traces are large: only the summaries above travel back

@@ -34,3 +34,4 @@ if key:
 json.dump(rec, open("$GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_traffic_journal-1pct.json", "w"), indent=1)
 print({k: rec.get(k) for k in ("kernel", "FETCH_SIZE_KB_mean", "WRITE_SIZE_KB_mean", "launches", "traffic_bytes_per_launch")})
 PY
+rm -rf $OUT  # raw traces are large: only the summaries above travel back

@@ -9,3 +9,4 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $GRAFT_R
 f=$(ls $OUT/*/*kernel_stats.csv | head -1)
 cp $f $GRAFT_REPO_ROOT/gpurun_out/${TAG}_kernel_stats.csv
 head -25 $f | cut -c1-160
+rm -rf $OUT  # raw traces are large: only the summaries above travel back
