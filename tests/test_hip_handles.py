@@ -143,3 +143,22 @@ def test_environment_defaults_put_the_unchanged_harness_on_the_fast_path(monkeyp
     alg.close()
     explicit = mmw(nit=20, eta=0.04, dtype="f64", rng="host")  # explicit arguments win over the environment
     assert (explicit.dtype, explicit.rng) == ("f64", "host")
+
+
+def test_lagged_plans_give_the_exact_plans_result(monkeypatch):
+    """Inside a chunk the exponential's plan is extrapolated from last iteration's matrix (row sums taken in k_dual_h, plan made
+    by a spare workgroup of k_softmax_b) and verified one iteration later.  The run must agree with the one that plans every
+    iteration exactly, to the tolerance of the exponential, without replays on a smoothly growing matrix."""
+    state = journal_graph(16, 0.02, seed=4)  # K = 2048
+    Z, nit = 24, 60
+    a = _lib.Solver(Z, state, nit, 0.04, dtype=_lib.F32)
+    a.iterate(nit, None, seed=9)
+    got = [a.read(f) for f in FIELDS]
+    assert a.read(_lib.F_BLOCKING)[3] == 0
+    a.close()
+    monkeypatch.setenv("MMW_NO_LAGGED_PLAN", "1")
+    b = _lib.Solver(Z, state, nit, 0.04, dtype=_lib.F32)
+    b.iterate(nit, None, seed=9)
+    for f, x in zip(FIELDS, got):
+        assert relerr(x, b.read(f)) < 2e-5, f
+    b.close()
