@@ -684,6 +684,15 @@ template <typename T> struct Solver final : mmw_solver {
         if (p.m_eff >= p.m_apriori) spare = 0;  // the a-priori order is never exceeded
         return std::min(eng.max_order, p.m_eff + spare);
     }
+    // Lagged planning pays where one Lanczos step is accepted with room to spare (its extrapolated norm bound is ~1/t larger than
+    // the exact one, which must not cost a second product: on graphs without locality a product is 10x the two kernels saved).
+    bool lagged_ok() const {
+        const ExpmPlan& p = eng.last;
+        if (!lagged_plan || !p.apost || p.m_eff != 1) return false;
+        union { unsigned u; float f; } e;
+        e.u = p.conv[1];
+        return (double)e.f <= p.tol / 2.0;
+    }
     int sketch_slabs() const { static const int cap = getenv("MMW_SK_SLABS") ? atoi(getenv("MMW_SK_SLABS")) : 256; return std::min(grid_rows(K), cap); }  // few slabs for the start-norm reduction
     int launch_sketch(hipStream_t s, uint64_t seed, uint32_t it) {
         const bool lz = eng.method == MMW_EXPM_LANCZOS;
@@ -703,6 +712,7 @@ template <typename T> struct Solver final : mmw_solver {
         const int gl = (int)std::min<size_t>(((size_t)H.nnzL() + BLOCK - 1) / BLOCK, (size_t)LOSS_GRID_MAX);  // LOSS: one thread per stored entry
         const int Dpad = eng.lay.Dpad;
         int m_launch = optimistic ? m_guess : 0;
+        const bool lag_chunk = optimistic && lagged_ok();  // from the plan the last settled chunk ended on
         bool xavg_deferred = false;
         // drawing the next sketch in extra workgroups of the SDDMM launch paid off with 8-wave SDDMM workgroups (+3.7 %); with
         // 16-wave ones (two per CU, every wave slot taken) it costs 1.5 %, so it is opt-in
@@ -717,7 +727,7 @@ template <typename T> struct Solver final : mmw_solver {
             // Lagged planning inside a chunk (not its first iteration, which plans exactly): k_dual_h also takes the row sums of the
             // L it walks over anyway -- last iteration's -- and one extra workgroup of k_softmax_b turns them into this iteration's plan
             // (extrapolated bounds, checked by the next plan): k_rowsums + k_plan leave the critical path.
-            const bool lagged_it = optimistic && it > 0 && eng.method == MMW_EXPM_LANCZOS && lagged_plan;
+            const bool lagged_it = optimistic && it > 0 && eng.method == MMW_EXPM_LANCZOS && lag_chunk;
             PlanArgs pa;
             if (lagged_it) {
                 pa.plan = eng.plan_d.p; pa.part = eng.row_part.p; pa.viol = eng.viol_d.p; pa.tol = eng.tol; pa.K = K; pa.method = eng.method;
@@ -863,7 +873,7 @@ template <typename T> struct Solver final : mmw_solver {
             MMW_TRY(record(3));
             ++iter;
         }
-        if (optimistic && n > 1 && lagged_plan && eng.method == MMW_EXPM_LANCZOS) {
+        if (optimistic && n > 1 && lag_chunk && eng.method == MMW_EXPM_LANCZOS) {
             // the chunk's last plan was extrapolated and no later plan of the chunk sees its matrix: check it here
             hipLaunchKernelGGL((k_rowsums<T>), dim3(eng.nwide), dim3(BLOCK), 0, st, K, d_indptr.p, d_col.p, lval.p, 0.5, eng.row_part.p);
             hipLaunchKernelGGL(k_plan_verify, dim3(1), dim3(PLAN_THREADS), 0, st, K, eng.row_part.p, eng.nwide, eng.plan_d.p, eng.viol_d.p, iter - 1);
