@@ -65,3 +65,11 @@ def test_dropin_overlay_resolves_to_this_solver():
         os.path.join(ROOT, "dropin"), ROOT)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr
+    # the harness writes mmw(nit=150, eta=0.04) (sim_script/journal_version/sim_mmw_time.py:34): the environment alone puts that
+    # unchanged call on the device-RNG / fp32 / warm-started path
+    code = ("import sys; sys.path[:0]=[%r, %r]; from sim_src.alg.mmw import mmw; a = mmw(nit=150, eta=0.04); "
+            "assert (a.dtype, a.rng, a.expm_tol, a.warm_start, a.round_batch) == ('f32', 'device', 1e-6, True, True), (a.dtype, a.rng); print('ok')") % (
+        os.path.join(ROOT, "dropin"), ROOT)
+    env = dict(os.environ, MMW_DTYPE="f32", MMW_RNG="device", MMW_EXPM_TOL="1e-6", MMW_WARM_START="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr

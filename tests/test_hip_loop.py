@@ -277,3 +277,25 @@ def test_matrix_core_spmm_steps_aside_when_the_norm_outgrows_the_split(monkeypat
     assert relerr(xa, b.read(_lib.F_XHALF)) < 1e-5
     assert relerr(a.read(_lib.F_LVAL), b.read(_lib.F_LVAL)) < 1e-5
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("rows,gt", [("32", "4"), ("32", "12"), ("64", "8"), ("20", "4")])
+def test_matrix_core_kernels_in_their_other_shapes(rows, gt, monkeypatch):
+    """Row blocks of at most 32 rows (one row tile: the 4-wave SpMM / SDDMM instantiations), wider column groups, blocks that
+    leave the second row tile half empty: same result as the fp32 LDS kernels."""
+    state = _journal_small()
+    Z, nit = 70, 3
+    monkeypatch.setenv("MMW_NO_MFMA", "1")
+    b = _lib.Solver(Z, state, nit, 0.04, dtype=_lib.F32)
+    b.iterate(nit, None, seed=2)
+    xh, xv = b.read(_lib.F_XHALF), b.read(_lib.F_XVAL)
+    b.close()
+    monkeypatch.delenv("MMW_NO_MFMA")
+    monkeypatch.setenv("MMW_MF_ROWS", rows)
+    monkeypatch.setenv("MMW_MF_GT", gt)
+    a = _lib.Solver(Z, state, nit, 0.04, dtype=_lib.F32)
+    assert a.read(_lib.F_SPMM_KIND)[0] == 3.0
+    a.iterate(nit, None, seed=2)
+    assert relerr(a.read(_lib.F_XHALF), xh) < 2e-6
+    assert relerr(a.read(_lib.F_XVAL), xv) < 3e-5
+    a.close()
