@@ -220,6 +220,7 @@ template <typename T> struct ExpmEngine {
     T* rownorm_d = nullptr;      // optional: the combination also emits ||y_row||^2 and its per-block sums (nblk slabs)
     double* rownorm_part = nullptr;
     unsigned short* out_planes = nullptr;  // optional (fp32): the combination also writes the result's bf16 hi / lo planes
+    bool planes_only = false;              // ... and nothing else: no one reads this application's fp32 result
     bool start_colsq_ready = false;  // the producer of the start block already filled `partial` with its column sums of squares (npart_start slabs)
     int npart_start = 0;
     // the a-posteriori stop rides on the shifted Lanczos epilogue of the half-tile and of the generic SpMM (not the full-tile one)
@@ -473,7 +474,8 @@ template <typename T> struct ExpmEngine {
                 MMW_TRY(kbegin(KT_KRYLOV_VEC));
                 const bool last = sub + 1 == nsub;
                 hipLaunchKernelGGL((k_lz_combine<T>), dim3(nwide), dim3(BLOCK), 0, st, K, Dpad, m, U.p, bs, Tm.p, S.coef, out, pd,
-                                   last ? rownorm_d : (T*)nullptr, last ? rownorm_part : (double*)nullptr, viol_d.p, last ? out_planes : (unsigned short*)nullptr);
+                                   last ? rownorm_d : (T*)nullptr, last ? rownorm_part : (double*)nullptr, viol_d.p, last ? out_planes : (unsigned short*)nullptr,
+                                   last && out_planes && planes_only ? 1 : 0);
                 MMW_TRY(kend());
             } else {
                 hipLaunchKernelGGL((k_copy<T>), dim3(gel), dim3(BLOCK), 0, st, bs, U.p, out);

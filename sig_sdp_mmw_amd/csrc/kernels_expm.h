@@ -1156,7 +1156,8 @@ __global__ __launch_bounds__(BLOCK) void k_lz_combine(int K, int Dpad, int m, co
                                                       const T* __restrict__ Tm, const double* __restrict__ coef, T* __restrict__ Yout,
                                                       ExpmPlan* __restrict__ plan, T* __restrict__ d,
                                                       double* __restrict__ dpart, int* __restrict__ viol,
-                                                      unsigned short* __restrict__ planes = nullptr) {
+                                                      unsigned short* __restrict__ planes = nullptr, int planes_only = 0) {
+    // planes_only: the only reader of this y is the matrix-core SDDMM (its two bf16 planes); the fp32 copy is not stored
     constexpr int VEC = V16<T>::N;
     __shared__ double sh[WAVES_PER_BLOCK];
     if (plan) {
@@ -1189,7 +1190,7 @@ __global__ __launch_bounds__(BLOCK) void k_lz_combine(int K, int Dpad, int m, co
                 x[v] = (T)s[v];
                 ss += (double)x[v] * (double)x[v];
             }
-            store16(Yout + o, x);
+            if (!planes_only) store16(Yout + o, x);
             if constexpr (sizeof(T) == 4) {
                 if (planes) {  // the matrix-core SDDMM reads y as two bf16 halves (kernels_mfma.h)
                     unsigned w4[4];
@@ -1335,9 +1336,9 @@ __host__ __device__ inline int plan_order(int method, double rho, double tol, in
 constexpr int PLAN_THREADS = 256;
 __device__ __forceinline__ void plan_body(int K, int method, int max_order, double tol, const double* __restrict__ part, int np,
                                           ExpmPlan* __restrict__ plan, int m_launch, int* __restrict__ viol, int apost, int iter_seen, int lagged,
-                                          double* sh /* [PLAN_THREADS / WAVE] */) {
+                                          double* sh /* one entry per wave of the workgroup */) {
     double tr = 0.0, pp = -1e300, pm = -1e300;
-    for (int i = threadIdx.x; i < np; i += PLAN_THREADS) {
+    for (int i = threadIdx.x; i < np; i += (int)blockDim.x) {
         tr += part[i];
         pp = part[np + i] > pp ? part[np + i] : pp;
         pm = part[2 * np + i] > pm ? part[2 * np + i] : pm;

@@ -74,11 +74,18 @@ template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_dual_h(PatternDev<T> P, const T* __restrict__ rsum, T* __restrict__ e_this,
                                                   T* __restrict__ e_accu, double eta, double* __restrict__ max_part,
                                                   const T* __restrict__ lval = nullptr, double lscale = 0.0,
-                                                  double* __restrict__ lpart = nullptr /* [3][grid], as k_rowsums */) {
-    __shared__ double sh[WAVES_PER_BLOCK];
+                                                  double* __restrict__ lpart = nullptr /* [3][grid], as k_rowsums */,
+                                                  const double* __restrict__ mref = nullptr, T* __restrict__ Yun = nullptr,
+                                                  T* __restrict__ wun = nullptr, double* __restrict__ sum_part = nullptr /* [4][grid] */) {
+    // With `mref` (the maximum of e_accu one iteration ago, left in scal[4]) the pass also does softmax pass A's work with that
+    // shift instead of this iteration's maximum: the softmax does not depend on the shift, and e_accu's maximum moves by
+    // eta * max e per iteration, so the exponentials stay far from overflow (k_dual_scal checks exactly that).  Yun / wun get
+    // exp(e_accu - mref) and the same over norm_H; k_dual_scal and the LOSS pass apply the normalisation.
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int K = P.K, Z = P.Z;
     double best = -1e300;
+    const double m0 = mref ? *mref : 0.0;
+    double sD = 0.0, sF = 0.0, sH = 0.0, sW = 0.0;
     double sd = 0.0, pp = -1e300, pm = -1e300;  // sums of L for the (lagged) plan of the exponential, when lval is given
     const int baseH = K + P.E_asso;
     for (int row = blockIdx.x * WAVES_PER_BLOCK + wib; row < K; row += gridDim.x * WAVES_PER_BLOCK) {
@@ -110,24 +117,46 @@ __global__ __launch_bounds__(BLOCK) void k_dual_h(PatternDev<T> P, const T* __re
             const T a = (T)((double)e_accu[baseH + row] + (double)(T)eh * eta);
             e_accu[baseH + row] = a;
             best = (double)a > best ? (double)a : best;
+            if (mref) {
+                const T ex = (T)exp((double)a - m0);
+                const double wn = (double)ex * (double)P.inv_norm_H[row];
+                Yun[baseH + row] = ex;
+                wun[row] = (T)wn;
+                sH += (double)ex;
+                sW += (double)P.cH[row] * wn;
+            }
         }
     }
     for (int c = blockIdx.x * BLOCK + threadIdx.x; c < baseH; c += gridDim.x * BLOCK) {
         const T a = (T)((double)e_accu[c] + (double)e_this[c] * eta);
         e_accu[c] = a;
         best = (double)a > best ? (double)a : best;
-    }
-    best = block_max(best, sh);
-    if (threadIdx.x == 0) max_part[blockIdx.x] = best;
-    if (lval) {
-        sd = block_sum(sd, sh);
-        pp = block_max(pp, sh);
-        pm = block_max(pm, sh);
-        if (threadIdx.x == 0) {
-            lpart[blockIdx.x] = sd;
-            lpart[gridDim.x + blockIdx.x] = pp;
-            lpart[2 * gridDim.x + blockIdx.x] = pm;
+        if (mref) {
+            const T ex = (T)exp((double)a - m0);
+            Yun[c] = ex;
+            if (c < K) sD += (double)ex;
+            else sF += (double)ex;
         }
+    }
+    // one LDS round for everything the block hands on: {max e_accu | L sums sd, pp, pm | softmax sums sD, sF, sH, sW}
+    __shared__ double shr[8][WAVES_PER_BLOCK];
+    best = wave_max(best);
+    if (lval) { sd = wave_sum(sd); pp = wave_max(pp); pm = wave_max(pm); }
+    if (mref) { sD = wave_sum(sD); sF = wave_sum(sF); sH = wave_sum(sH); sW = wave_sum(sW); }
+    if (lane == 0) {
+        shr[0][wib] = best;
+        shr[1][wib] = sd; shr[2][wib] = pp; shr[3][wib] = pm;
+        shr[4][wib] = sD; shr[5][wib] = sF; shr[6][wib] = sH; shr[7][wib] = sW;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const int q = threadIdx.x;
+        const bool is_max = q == 0 || q == 2 || q == 3;
+        double t = shr[q][0];
+        for (int w = 1; w < WAVES_PER_BLOCK; ++w) t = is_max ? (shr[q][w] > t ? shr[q][w] : t) : t + shr[q][w];
+        if (q == 0) max_part[blockIdx.x] = t;
+        else if (q < 4) { if (lval) lpart[(q - 1) * gridDim.x + blockIdx.x] = t; }
+        else if (mref) sum_part[(q - 4) * gridDim.x + blockIdx.x] = t;
     }
 }
 
@@ -176,7 +205,7 @@ __global__ __launch_bounds__(BLOCK) void k_softmax_b(int C, T* __restrict__ Y, T
                                                      const double* __restrict__ sum_part, int npart,
                                                      double* __restrict__ scal /* [4] */, int baseH, const T* __restrict__ inv_norm_H,
                                                      T* __restrict__ wH /* [K]: Y_H / norm_H, the weight the LOSS gathers */,
-                                                     PlanArgs pa = PlanArgs{}) {
+                                                     PlanArgs pa = PlanArgs{}, const double* __restrict__ max_part = nullptr, int nmax = 0) {
     __shared__ double sh[WAVES_PER_BLOCK];
     if (pa.plan && blockIdx.x == gridDim.x - 1) {
         // one extra workgroup makes the exponential's plan from the row sums k_dual_h left two launches ago (lagged planning)
@@ -197,11 +226,51 @@ __global__ __launch_bounds__(BLOCK) void k_softmax_b(int C, T* __restrict__ Y, T
         if (accumulate) yavg[c] += y;
         if (c >= baseH) wH[c - baseH] = (T)((double)y * (double)inv_norm_H[c - baseH]);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        scal[0] = s[0] / total;
-        scal[1] = s[1] / total;
-        scal[2] = s[3] / total;
+    if (blockIdx.x == 0) {
+        double m = -1e300;
+        for (int i = threadIdx.x; i < nmax; i += BLOCK) m = max_part[i] > m ? max_part[i] : m;
+        m = block_max(m, sh);
+        if (threadIdx.x == 0) {
+            scal[0] = s[0] / total;
+            scal[1] = s[1] / total;
+            scal[2] = s[3] / total;
+            scal[3] = total;
+            if (max_part) scal[4] = m;  // the shift the next iteration's fused pass may use (k_dual_h, mref)
+        }
+    }
+}
+
+// ---- the fused pass's scalars: one workgroup folds the per-block sums and maxima k_dual_h (mref form) left into what softmax pass
+// B leaves in `scal`, and flags a maximum that ran away from the shift (the exponentials may have overflowed: the chunk is
+// replayed on the two-pass kernels).
+constexpr int DSCAL_THREADS = 1024;
+__global__ __launch_bounds__(DSCAL_THREADS) void k_dual_scal(const double* __restrict__ sum_part, const double* __restrict__ max_part, int npart,
+                                                            double* __restrict__ scal /* [5] */, double overflow_gap, int* __restrict__ viol) {
+    __shared__ double sh[5][DSCAL_THREADS / WAVE];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, m = -1e300;
+    for (int i = threadIdx.x; i < npart; i += DSCAL_THREADS) {
+        const double a0 = sum_part[i], a1 = sum_part[npart + i], a2 = sum_part[2 * npart + i], a3 = sum_part[3 * npart + i], b = max_part[i];
+        s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+        m = b > m ? b : m;
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3); m = wave_max(m);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[0][w] = s0; sh[1][w] = s1; sh[2][w] = s2; sh[3][w] = s3; sh[4][w] = m; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s0 = s1 = s2 = s3 = 0.0; m = -1e300;
+        for (int i = 0; i < DSCAL_THREADS / WAVE; ++i) {
+            s0 += sh[0][i]; s1 += sh[1][i]; s2 += sh[2][i]; s3 += sh[3][i];
+            m = sh[4][i] > m ? sh[4][i] : m;
+        }
+        const double total = s0 + s1 + s2;
+        const double m0 = scal[4];
+        scal[0] = s0 / total;
+        scal[1] = s1 / total;
+        scal[2] = s3 / total;
         scal[3] = total;
+        scal[4] = m;
+        if (!(m - m0 <= overflow_gap) || !(total > 0.0) || !(total < 1e300)) *viol = 1;
     }
 }
 
@@ -220,29 +289,48 @@ __global__ __launch_bounds__(BLOCK) void k_loss(PatternDev<T> P, const int* __re
                                                 double eta, const int* __restrict__ bpos, T* __restrict__ lval_blk,
                                                 const T* __restrict__ xval = nullptr, T* __restrict__ xavg = nullptr,
                                                 SketchArgs<T> sk = SketchArgs<T>{}, int Dpad = 0, const int* __restrict__ fpos = nullptr,
-                                                unsigned* __restrict__ afrag = nullptr) {
+                                                unsigned* __restrict__ afrag = nullptr, T* __restrict__ Ynorm = nullptr,
+                                                T* __restrict__ yavg = nullptr, int accumulate = 0, PlanArgs pa = PlanArgs{}) {
+    // Ynorm != nullptr: Y and wH hold the unnormalised exponentials of the fused DUAL pass (k_dual_h, mref form) and scal[3]
+    // their total; this pass divides where it uses them and writes the normalised Y (and its running sum) on the side.
     if ((int)blockIdx.x < sk.nblocks) {  // leading workgroups draw this iteration's sketch (same shape as k_sketch_rng: same bits)
         extern __shared__ __attribute__((aligned(16))) char smem_raw[];
         sketch_rows<T, WAVES_PER_BLOCK>(sk.K, sk.D, Dpad, sk.seed, sk.iter, sk.R, sk.colsq_part, (int)blockIdx.x, sk.nblocks,
                                         reinterpret_cast<double*>(smem_raw), sk.planes);
         return;
     }
-    const int bid = (int)blockIdx.x - sk.nblocks, nb = (int)gridDim.x - sk.nblocks;
+    const int lead = sk.nblocks + (pa.plan ? 1 : 0);
+    if (pa.plan && (int)blockIdx.x == sk.nblocks) {
+        // one more workgroup plans the exponential this matrix update is followed by, from the row sums k_dual_h took (lagged planning)
+        __shared__ double shp[WAVES_PER_BLOCK];
+        plan_body(pa.K, pa.method, pa.max_order, pa.tol, pa.part, pa.np, pa.plan, pa.m_launch, pa.viol, pa.apost, pa.iter_seen, 1, shp);
+        return;
+    }
+    const int bid = (int)blockIdx.x - lead, nb = (int)gridDim.x - lead;
     const int K = P.K, Z = P.Z, baseF = K;
     const double invK = 1.0 / (double)K, Zm1 = (double)(Z - 1);
     const double cF = 0.5 + 1.0 / ((double)K * Zm1);
     const double sumYD = scal[0], sumYF = scal[1], sumW = scal[2];
     const double dconst = -(sumYD * invK) / (1.0 - invK) + (sumYF / ((double)K * Zm1)) / cF - sumW;
-    const double gscale = Zm1 / (double)(2 * Z);
+    const double total = Ynorm ? scal[3] : 1.0, inv_total = 1.0 / total;
+    const double gscale = (Zm1 / (double)(2 * Z)) * inv_total;
+    if (Ynorm)
+        for (int c = bid * BLOCK + threadIdx.x; c < P.C; c += nb * BLOCK) {
+            const T y = (T)((double)Y[c] / total);
+            Ynorm[c] = y;
+            if (accumulate) yavg[c] += y;
+        }
     for (int e = bid * BLOCK + threadIdx.x; e < P.nnzL; e += nb * BLOCK) {
         const int row = lrow[e], c = P.col[e];
         double add;
         if (c == row) {
-            add = (double)Y[row] / (1.0 - invK) + dconst;
+            const double y = Ynorm ? (double)(T)((double)Y[row] / total) : (double)Y[row];
+            add = y / (1.0 - invK) + dconst;
         } else if (P.pid[e] >= 0) {
-            add = ((double)Y[baseF + P.pid[e]] * 0.5) / cF;
+            const double y = Ynorm ? (double)(T)((double)Y[baseF + P.pid[e]] / total) : (double)Y[baseF + P.pid[e]];
+            add = (y * 0.5) / cF;
         } else {
-            const double w_row = (double)wH[row], w_col = (double)wH[c];  // one gather per side (softmax pass B made Y_H / norm_H)
+            const double w_row = (double)wH[row], w_col = (double)wH[c];  // one gather per side (Y_H / norm_H from the DUAL phase)
             add = ((double)P.sab[e] * w_col + (double)P.sba[e] * w_row) * gscale;  // column-scaled S_T' symmetrised
         }
         const T nv = (T)((double)lval[e] - eta * add);

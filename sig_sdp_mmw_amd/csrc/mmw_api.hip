@@ -56,6 +56,8 @@ template <typename T> struct Solver final : mmw_solver {
     DevBuf<T> lval, xval, xavg, Y, yavg, e_accu, e_this, rsum, Xh, drow;
     DevBuf<double> max_part, sum_part, scal, tr_part, stage64, out64;
     DevBuf<T> wH;  // Y_H / norm_H
+    DevBuf<T> yun;  // the fused DUAL pass's unnormalised exponentials (see iterate_impl)
+    const bool fuse_dual = getenv("MMW_NO_FUSED_DUAL") == nullptr;
     static constexpr int LOSS_GRID_MAX = 4096;
     // locality blocking (blocking.h)
     HostBlocking HB;
@@ -193,7 +195,7 @@ template <typename T> struct Solver final : mmw_solver {
         MMW_TRY(lval.alloc(nnz)); MMW_TRY(xval.alloc(nnz)); MMW_TRY(xavg.alloc(nnz));
         MMW_TRY(Y.alloc(C)); MMW_TRY(yavg.alloc(C)); MMW_TRY(e_accu.alloc(C)); MMW_TRY(e_this.alloc(C));
         MMW_TRY(rsum.alloc(K)); MMW_TRY(drow.alloc(K));
-        MMW_TRY(max_part.alloc(ROW_GRID_MAX)); MMW_TRY(sum_part.alloc(4 * 2048)); MMW_TRY(scal.alloc(4));
+        MMW_TRY(max_part.alloc(ROW_GRID_MAX)); MMW_TRY(sum_part.alloc(4 * (size_t)std::max(2048, ROW_GRID_MAX))); MMW_TRY(scal.alloc(8));
         MMW_TRY(tr_part.alloc(ROW_GRID_MAX)); MMW_TRY(wH.alloc(K));
         MMW_TRY(eng.init(st, K, D, d_indptr.p, d_col.p, lval.p));
         kt.st = st;
@@ -733,11 +735,23 @@ template <typename T> struct Solver final : mmw_solver {
                 pa.plan = eng.plan_d.p; pa.part = eng.row_part.p; pa.viol = eng.viol_d.p; pa.tol = eng.tol; pa.K = K; pa.method = eng.method;
                 pa.max_order = eng.max_order; pa.np = gr; pa.m_launch = m_launch; pa.apost = eng.apost() ? 1 : 0; pa.iter_seen = iter - 1;
             }
-            hipLaunchKernelGGL((k_dual_h<T>), dim3(gr), dim3(BLOCK), 0, st, P, rsum.p, e_this.p, e_accu.p, eta, max_part.p,
-                               (const T*)(lagged_it ? lval.p : nullptr), 0.5, eng.row_part.p);
-            hipLaunchKernelGGL((k_softmax_a<T>), dim3(gc), dim3(BLOCK), 0, st, P, e_accu.p, Y.p, max_part.p, gr, sum_part.p);
-            hipLaunchKernelGGL((k_softmax_b<T>), dim3(gc + (lagged_it ? 1 : 0)), dim3(BLOCK), 0, st, C, Y.p, yavg.p, acc, sum_part.p, gc, scal.p,
-                               K + (int)H.E_asso(), d_invn.p, wH.p, pa);
+            // Inside a chunk (not its first iteration) the softmax rides in k_dual_h, shifted by the previous iteration's maximum
+            // instead of this one's: one small workgroup then folds the sums, and the LOSS pass normalises where it reads
+            // (kernels_loop.h, k_dual_h / k_dual_scal).  Two launches of the dependent chain fewer.
+            const bool fused_dual = optimistic && it > 0 && fuse_dual;
+            if (fused_dual) {
+                if (yun.n < (size_t)C) MMW_TRY(yun.alloc((size_t)C));
+                hipLaunchKernelGGL((k_dual_h<T>), dim3(gr), dim3(BLOCK), 0, st, P, rsum.p, e_this.p, e_accu.p, eta, max_part.p,
+                                   (const T*)(lagged_it ? lval.p : nullptr), 0.5, eng.row_part.p, (const double*)(scal.p + 4), yun.p, wH.p, sum_part.p);
+                hipLaunchKernelGGL(k_dual_scal, dim3(1), dim3(DSCAL_THREADS), 0, st, sum_part.p, max_part.p, gr, scal.p,
+                                   sizeof(T) == 4 ? 60.0 : 600.0, eng.viol_d.p);
+            } else {
+                hipLaunchKernelGGL((k_dual_h<T>), dim3(gr), dim3(BLOCK), 0, st, P, rsum.p, e_this.p, e_accu.p, eta, max_part.p,
+                                   (const T*)(lagged_it ? lval.p : nullptr), 0.5, eng.row_part.p);
+                hipLaunchKernelGGL((k_softmax_a<T>), dim3(gc), dim3(BLOCK), 0, st, P, e_accu.p, Y.p, max_part.p, gr, sum_part.p);
+                hipLaunchKernelGGL((k_softmax_b<T>), dim3(gc + (lagged_it ? 1 : 0)), dim3(BLOCK), 0, st, C, Y.p, yavg.p, acc, sum_part.p, gc, scal.p,
+                                   K + (int)H.E_asso(), d_invn.p, wH.p, pa, max_part.p, gr);
+            }
             MMW_TRY(kt.end());
             MMW_TRY(record(1));
             // ---- LOSS
@@ -758,10 +772,12 @@ template <typename T> struct Solver final : mmw_solver {
             // the blocked copy of L feeds the fp32 LDS kernel only: while the matrix-core kernel runs the products it is left stale
             const bool mf_it = eng.mfma_now() && eng.method == MMW_EXPM_LANCZOS;
             if (mf_it) lblk_stale = true;
-            hipLaunchKernelGGL((k_loss<T>), dim3(gl + skl.nblocks), dim3(BLOCK), skl.nblocks && lz_m ? (size_t)WAVES_PER_BLOCK * Dpad * sizeof(double) : 0,
-                               st, P, d_lrow.p, Y.p, wH.p, scal.p, lval.p, eta, (const int*)(eng.use_blk && !mf_it ? b_bpos.p : nullptr), lval_blk.p,
+            const PlanArgs pl_loss = fused_dual ? pa : PlanArgs{};  // the fused pass has no softmax pass B to lend the planning a workgroup
+            hipLaunchKernelGGL((k_loss<T>), dim3(gl + skl.nblocks + (pl_loss.plan ? 1 : 0)), dim3(BLOCK), skl.nblocks && lz_m ? (size_t)WAVES_PER_BLOCK * Dpad * sizeof(double) : 0,
+                               st, P, d_lrow.p, fused_dual ? yun.p : Y.p, wH.p, scal.p, lval.p, eta,
+                               (const int*)(eng.use_blk && !mf_it ? b_bpos.p : nullptr), lval_blk.p,
                                (const T*)(xavg_deferred ? xval.p : nullptr), xavg_deferred ? xavg.p : (T*)nullptr, skl, Dpad,
-                               (const int*)(eng.use_mfma ? b_fpos.p : nullptr), afrag.p);
+                               (const int*)(eng.use_mfma ? b_fpos.p : nullptr), afrag.p, fused_dual ? Y.p : (T*)nullptr, yavg.p, acc, pl_loss);
             xavg_deferred = false;
             MMW_TRY(kt.end());
             MMW_TRY(record(2));
@@ -792,6 +808,8 @@ template <typename T> struct Solver final : mmw_solver {
                     eng.out_planes = xh_planes.p;
                 }
             }
+            // inside a chunk only the SDDMM reads X_half; the chunk's last iteration leaves the fp32 copy the API hands out
+            eng.planes_only = eng.out_planes != nullptr && optimistic && it + 1 < n && !getenv("MMW_KEEP_XHALF");
             eng.rownorm_d = drow.p;  // the Lanczos combination also emits the row norms and the trace slabs
             eng.rownorm_part = tr_part.p;
             eng.plan_iter = iter;
