@@ -58,6 +58,9 @@ template <typename T> struct Solver final : mmw_solver {
     DevBuf<T> wH;  // Y_H / norm_H
     DevBuf<T> yun;  // the fused DUAL pass's unnormalised exponentials (see iterate_impl)
     const bool fuse_dual = getenv("MMW_NO_FUSED_DUAL") == nullptr;
+    // how far e_accu's maximum may run ahead of the fused pass's shift before its exponentials are distrusted (exp overflows T
+    // near 88 / 709); MMW_DUAL_GAP is for the tests, which force the replay with it
+    const double dual_gap = getenv("MMW_DUAL_GAP") ? atof(getenv("MMW_DUAL_GAP")) : (sizeof(T) == 4 ? 60.0 : 600.0);
     static constexpr int LOSS_GRID_MAX = 4096;
     // locality blocking (blocking.h)
     HostBlocking HB;
@@ -744,7 +747,7 @@ template <typename T> struct Solver final : mmw_solver {
                 hipLaunchKernelGGL((k_dual_h<T>), dim3(gr), dim3(BLOCK), 0, st, P, rsum.p, e_this.p, e_accu.p, eta, max_part.p,
                                    (const T*)(lagged_it ? lval.p : nullptr), 0.5, eng.row_part.p, (const double*)(scal.p + 4), yun.p, wH.p, sum_part.p);
                 hipLaunchKernelGGL(k_dual_scal, dim3(1), dim3(DSCAL_THREADS), 0, st, sum_part.p, max_part.p, gr, scal.p,
-                                   sizeof(T) == 4 ? 60.0 : 600.0, eng.viol_d.p);
+                                   dual_gap, eng.viol_d.p);
             } else {
                 hipLaunchKernelGGL((k_dual_h<T>), dim3(gr), dim3(BLOCK), 0, st, P, rsum.p, e_this.p, e_accu.p, eta, max_part.p,
                                    (const T*)(lagged_it ? lval.p : nullptr), 0.5, eng.row_part.p);

@@ -162,3 +162,46 @@ def test_lagged_plans_give_the_exact_plans_result(monkeypatch):
     for f, x in zip(FIELDS, got):
         assert relerr(x, b.read(f)) < 2e-5, f
     b.close()
+
+
+@pytest.mark.parametrize("dtype,tol", [(_lib.F32, 2e-5), (_lib.F64, 1e-9)])
+def test_fused_dual_pass_gives_the_two_pass_softmax(dtype, tol, monkeypatch):
+    """Inside a chunk the softmax rides in k_dual_h, shifted by the previous iteration's maximum, and the LOSS pass normalises
+    (k_dual_scal folds the sums).  The softmax does not depend on the shift: the run agrees with the two-pass kernels to rounding,
+    and with no replay."""
+    state = journal_graph(16, 0.02, seed=4)
+    Z, nit = 24, 60
+    a = _lib.Solver(Z, state, nit, 0.04, dtype=dtype)
+    a.iterate(nit, None, seed=9)
+    got = [a.read(f) for f in FIELDS]
+    assert a.read(_lib.F_BLOCKING)[3] == 0
+    a.close()
+    monkeypatch.setenv("MMW_NO_FUSED_DUAL", "1")
+    b = _lib.Solver(Z, state, nit, 0.04, dtype=dtype)
+    b.iterate(nit, None, seed=9)
+    for f, x in zip(FIELDS, got):
+        assert relerr(x, b.read(f)) < tol, f
+    b.close()
+
+
+def test_fused_dual_pass_is_replayed_when_the_maximum_runs_away(monkeypatch):
+    """k_dual_scal distrusts the fused pass's exponentials when e_accu's maximum has moved further from the shift than exp can
+    absorb; with the allowance forced negative every chunk is restored and replayed on the two-pass kernels, and the result is
+    the run that never took the fused pass."""
+    state = journal_graph(16, 0.02, seed=4)
+    Z, nit = 24, 30
+    monkeypatch.setenv("MMW_NO_LAGGED_PLAN", "1")
+    monkeypatch.setenv("MMW_DUAL_GAP", "-1")
+    a = _lib.Solver(Z, state, nit, 0.04, dtype=_lib.F32)
+    a.iterate(nit, None, seed=9)
+    got = [a.read(f) for f in FIELDS]
+    assert a.read(_lib.F_BLOCKING)[3] > 0  # replays
+    a.close()
+    monkeypatch.delenv("MMW_DUAL_GAP")
+    monkeypatch.setenv("MMW_SYNC_PLAN", "1")
+    b = _lib.Solver(Z, state, nit, 0.04, dtype=_lib.F32)
+    b.iterate(nit, None, seed=9)
+    assert b.read(_lib.F_BLOCKING)[3] == 0
+    for f, x in zip(FIELDS, got):
+        assert relerr(x, b.read(f)) < 1e-6, f  # as in test_replayed_chunk_equals_the_synchronous_run
+    b.close()
