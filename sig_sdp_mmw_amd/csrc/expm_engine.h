@@ -219,7 +219,7 @@ template <typename T> struct ExpmEngine {
     std::function<int()> blk_refresh;  // rebuilds val_blk from the CSR values
     T* rownorm_d = nullptr;      // optional: the combination also emits ||y_row||^2 and its per-block sums (nblk slabs)
     double* rownorm_part = nullptr;
-    unsigned short* out_planes = nullptr;  // optional (fp32): the combination also writes the result's bf16 hi / lo planes
+    unsigned short* out_planes = nullptr;  // optional (fp32): the combination also writes the result as bf16 hi / lo halves, interleaved per 32 columns (k_sddmm_mfma)
     bool planes_only = false;              // ... and nothing else: no one reads this application's fp32 result
     bool start_colsq_ready = false;  // the producer of the start block already filled `partial` with its column sums of squares (npart_start slabs)
     int npart_start = 0;

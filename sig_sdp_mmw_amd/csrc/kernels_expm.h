@@ -1201,8 +1201,11 @@ __global__ __launch_bounds__(BLOCK) void k_lz_combine(int K, int Dpad, int m, co
                         const unsigned short lo = __builtin_bit_cast(unsigned short, (__bf16)(xf - __uint_as_float((unsigned)hi << 16)));
                         w4[v] = ((unsigned)hi << 16) | lo;
                     }
-                    reinterpret_cast<uint2*>(planes)[o >> 2] = make_uint2((w4[0] >> 16) | (w4[1] & 0xFFFF0000u), (w4[2] >> 16) | (w4[3] & 0xFFFF0000u));
-                    reinterpret_cast<uint2*>(planes + (size_t)K * Dpad)[o >> 2] = make_uint2((w4[0] & 0xFFFFu) | (w4[1] << 16), (w4[2] & 0xFFFFu) | (w4[3] << 16));
+                    // interleaved per 32 columns: 32 hi halves, then the 32 lo halves (the layout k_sddmm_mfma gathers whole lines of)
+                    const int col = p * VEC;
+                    unsigned short* g = planes + (size_t)row * Dpad * 2 + (size_t)(col >> 5) * 64 + (col & 31);
+                    *reinterpret_cast<uint2*>(g) = make_uint2((w4[0] >> 16) | (w4[1] & 0xFFFF0000u), (w4[2] >> 16) | (w4[3] & 0xFFFF0000u));
+                    *reinterpret_cast<uint2*>(g + 32) = make_uint2((w4[0] & 0xFFFFu) | (w4[1] << 16), (w4[2] & 0xFFFFu) | (w4[3] << 16));
                 }
             }
         }

@@ -367,10 +367,12 @@ void k_spmm_mfma(MfmaDev M, int Dpad, size_t plane_bytes, const char* __restrict
 // (written by the Lanczos combination), then only the pattern's entries of every tile are divided by the trace and stored.
 // Both operands are k-contiguous here (k runs along a row of Y), so fragments are plain 16-byte LDS reads, no transpose.
 // One workgroup = (row block, 4 union tiles = 128 union rows): 4 MT waves, wave (wm, wn) owns row tile wm x union tile wn.
-// A chunk = 32 columns of Y (2 k-steps, 64 bytes per row and plane) of the block's 32 MT rows and of the 128 union rows, brought
-// in by LDS-DMA like the SpMM's chunks; a row's four 16-byte slots are rotated by (row >> 2) -- applied on the DMA's source
-// side -- so that the 16 lanes of a ds_read_b128 service group, which read 16 different rows at the same slot, hit 16 different
-// bank quads.  The diagonal comes from the exact row norms the combination made (d / tr), not from the split product.
+// Y comes as bf16 halves interleaved per 32 columns: a row's 128-byte group g holds the hi halves of columns 32 g .. 32 g + 31
+// (64 bytes) and then their lo halves (k_lz_combine writes it so), so that a chunk = 32 columns of Y (2 k-steps) is one full
+// 128-byte line per row, of the block's 32 MT rows and of the 128 union rows, brought in by LDS-DMA like the SpMM's chunks.
+// A row's eight 16-byte slots are rotated by (row >> 1) -- applied on the DMA's source side -- so that the 16 lanes of a
+// ds_read_b128 service group, which read 16 different rows at the same slot, hit 16 different bank quads.
+// The diagonal comes from the exact row norms the combination made (d / tr), not from the split product.
 // Error of an off-diagonal entry: <= 3 * 2^-17 |y_a| |y_b| (the two-half split), i.e. ~1e-5 of the diagonal scale.
 struct SdMfmaDev {
     const int* tbase;             // [nb+1] first tile of each block
@@ -379,19 +381,19 @@ struct SdMfmaDev {
     const int* tepos;             // CSR position
 };
 constexpr int SDM_GT = 4;   // union tiles per workgroup
-constexpr int SDM_KC = 2;   // k-steps per chunk (64 bytes per row and plane)
+constexpr int SDM_KC = 2;   // k-steps per chunk (a 128-byte line per row: 64 bytes of hi halves, 64 of lo halves)
 template <int MT> constexpr int sdm_rows() { return 32 * MT + 32 * SDM_GT; }
 template <int MT> constexpr int sdm_chunk_bytes() { return 2 * sdm_rows<MT>() * 32 * SDM_KC; }
 template <int MT> constexpr int sdm_lds_bytes() { return sdm_rows<MT>() * 4 + 2 * sdm_chunk_bytes<MT>(); }
 
 template <int MT>
 __global__ __launch_bounds__(4 * MT * 64)
-void k_sddmm_mfma(MfmaDev M, SdMfmaDev S, int K, int Dpad, size_t plane_bytes, const char* __restrict__ Ypl, const float* __restrict__ d,
+void k_sddmm_mfma(MfmaDev M, SdMfmaDev S, int K, int Dpad, const char* __restrict__ Ypl, const float* __restrict__ d,
                   const double* __restrict__ tr_part, int ntr, const int* __restrict__ diag_pos, float* __restrict__ xval) {
     constexpr int NW = 4 * MT, THREADS = NW * 64;
     constexpr int RA = 32 * MT, R = sdm_rows<MT>();
     constexpr int CHUNK = sdm_chunk_bytes<MT>();
-    constexpr int NP = 2 * R / 16;  // 1-KiB pieces per chunk: 16 rows x 64 bytes
+    constexpr int NP = R / 8;  // 1-KiB pieces per chunk: 8 rows x 128 bytes
     constexpr int NJ = (NP + NW - 1) / NW;
     typedef __attribute__((address_space(3))) void* lds_vp;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -428,19 +430,18 @@ void k_sddmm_mfma(MfmaDev M, SdMfmaDev S, int K, int Dpad, size_t plane_bytes, c
     for (int w = 0; w < NW; ++w) tr += sh_tr[w];
     tr /= (double)K;
 
-    // DMA pieces of this wave: piece i = wv + NW j covers plane i / (R / 16), rows 16 g .. 16 g + 15; lane L -> row 16 g + (L >> 2),
-    // position L & 3, which holds source slot (position - (row >> 2)) & 3 of the row's 64-byte chunk segment
-    const unsigned pitch = (unsigned)Dpad * 2u;
+    // DMA pieces of this wave: piece i = wv + NW j covers rows 8 i .. 8 i + 7; lane L -> row 8 i + (L >> 3), position L & 7,
+    // which holds source slot (position - (row >> 1)) & 7 of the row's 128-byte chunk line (slots 0-3 hi halves, 4-7 lo halves)
+    const unsigned pitch = (unsigned)Dpad * 4u;
     const char* pbase[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int i = wv + NW * j;
         pbase[j] = Ypl;
         if (i < NP) {
-            const int p = i / (R / 16), g = i - p * (R / 16);
-            const int row = 16 * g + (lane >> 2), pos = lane & 3;
-            const int slot = (pos - (row >> 2)) & 3;
-            pbase[j] = Ypl + ((size_t)p * plane_bytes + (size_t)(unsigned)rows_l[row] * pitch + (size_t)slot * 16u);
+            const int row = 8 * i + (lane >> 3), pos = lane & 7;
+            const int slot = (pos - (row >> 1)) & 7;
+            pbase[j] = Ypl + ((size_t)(unsigned)rows_l[row] * pitch + (size_t)slot * 16u);
         }
     }
     const int cw = wv < NP ? (NP - wv + NW - 1) / NW : 0;
@@ -448,19 +449,20 @@ void k_sddmm_mfma(MfmaDev M, SdMfmaDev S, int K, int Dpad, size_t plane_bytes, c
         const unsigned dst_l = bufs_l + (unsigned)((c & 1) * CHUNK);
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-            if (j < cw) mf_dma16(pbase[j] + (size_t)c * (32 * SDM_KC), dst_l + (unsigned)((wv + NW * j) * 1024));
+            if (j < cw) mf_dma16(pbase[j] + (size_t)c * (64 * SDM_KC), dst_l + (unsigned)((wv + NW * j) * 1024));
     };
-    // fragment addresses: lane (r = lane & 31, h = lane >> 5) reads row `ra` (A) / `rbw` (B), slot 2 kk + h, stored at
-    // position (slot + (row >> 2)) & 3
+    // fragment addresses: lane (r = lane & 31, h = lane >> 5) reads row `ra` (A) / `rbw` (B), slot 4 p + 2 kk + h of half p,
+    // stored at position (slot + (row >> 1)) & 7
     const int r = lane & 31, h = lane >> 5;
     const int ra = 32 * wm + r, rbw = RA + 32 * wn + r;
-    unsigned offA[SDM_KC], offB[SDM_KC];
+    unsigned offA[SDM_KC][2], offB[SDM_KC][2];
 #pragma unroll
-    for (int kk = 0; kk < SDM_KC; ++kk) {
-        offA[kk] = (unsigned)(ra * 64 + (((2 * kk + h) + (ra >> 2)) & 3) * 16);
-        offB[kk] = (unsigned)(rbw * 64 + (((2 * kk + h) + (rbw >> 2)) & 3) * 16);
-    }
-    constexpr unsigned PLANE_L = (unsigned)(R * 64);
+    for (int kk = 0; kk < SDM_KC; ++kk)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            offA[kk][p] = (unsigned)(ra * 128 + (((4 * p + 2 * kk + h) + (ra >> 1)) & 7) * 16);
+            offB[kk][p] = (unsigned)(rbw * 128 + (((4 * p + 2 * kk + h) + (rbw >> 1)) & 7) * 16);
+        }
     mf_f16 acc;
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[v] = 0.f;
@@ -473,10 +475,10 @@ void k_sddmm_mfma(MfmaDev M, SdMfmaDev S, int K, int Dpad, size_t plane_bytes, c
         const char* cb = bufs + (c & 1) * CHUNK;
 #pragma unroll
         for (int kk = 0; kk < SDM_KC; ++kk) {
-            const uint4 ah = *reinterpret_cast<const uint4*>(cb + offA[kk]);
-            const uint4 al = *reinterpret_cast<const uint4*>(cb + PLANE_L + offA[kk]);
-            const uint4 bh = *reinterpret_cast<const uint4*>(cb + offB[kk]);
-            const uint4 bl = *reinterpret_cast<const uint4*>(cb + PLANE_L + offB[kk]);
+            const uint4 ah = *reinterpret_cast<const uint4*>(cb + offA[kk][0]);
+            const uint4 al = *reinterpret_cast<const uint4*>(cb + offA[kk][1]);
+            const uint4 bh = *reinterpret_cast<const uint4*>(cb + offB[kk][0]);
+            const uint4 bl = *reinterpret_cast<const uint4*>(cb + offB[kk][1]);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mf_bf8, al), __builtin_bit_cast(mf_bf8, bh), acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mf_bf8, ah), __builtin_bit_cast(mf_bf8, bl), acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mf_bf8, ah), __builtin_bit_cast(mf_bf8, bh), acc, 0, 0, 0);

@@ -829,11 +829,11 @@ template <typename T> struct Solver final : mmw_solver {
                     static bool attr1 = false, attr2 = false;
                     if (HB.mfma_mt == 2) {
                         if (!attr2) { MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sddmm_mfma<2>), hipFuncAttributeMaxDynamicSharedMemorySize, sdm_lds_bytes<2>())); attr2 = true; }
-                        hipLaunchKernelGGL((k_sddmm_mfma<2>), grid, dim3(512), sdm_lds_bytes<2>(), st, eng.mf, SM, K, Dpad, eng.bs * sizeof(unsigned short),
+                        hipLaunchKernelGGL((k_sddmm_mfma<2>), grid, dim3(512), sdm_lds_bytes<2>(), st, eng.mf, SM, K, Dpad,
                                            reinterpret_cast<const char*>(xh_planes.p), drow.p, tr_part.p, gr, d_diag.p, xval.p);
                     } else {
                         if (!attr1) { MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sddmm_mfma<1>), hipFuncAttributeMaxDynamicSharedMemorySize, sdm_lds_bytes<1>())); attr1 = true; }
-                        hipLaunchKernelGGL((k_sddmm_mfma<1>), grid, dim3(256), sdm_lds_bytes<1>(), st, eng.mf, SM, K, Dpad, eng.bs * sizeof(unsigned short),
+                        hipLaunchKernelGGL((k_sddmm_mfma<1>), grid, dim3(256), sdm_lds_bytes<1>(), st, eng.mf, SM, K, Dpad,
                                            reinterpret_cast<const char*>(xh_planes.p), drow.p, tr_part.p, gr, d_diag.p, xval.p);
                     }
                     sd_done = true;
