@@ -103,7 +103,51 @@ template <typename T> struct DenseWork {
         return MMW_OK;
     }
     // Jacobi of G (b x b) -> eigenvalues in `diag`, eigenvectors in Q (one launch per round, ping-pong buffers)
+    DevBuf<double> bjH[2], bjQ[2], bjR;
+    // block Jacobi (kernels_dense.h, k_bj_solve / k_bj_apply): two launches per block round, M - 1 block rounds per sweep
+    int jacobi_blocked(int b, double rel_tol, int max_sweeps, int* sweeps_done) {
+        int M = (b + BJ_NB - 1) / BJ_NB;
+        M = std::max(2, M + (M & 1));
+        const int P = BJ_NB * M;
+        const size_t pp = (size_t)P * P;
+        for (int q = 0; q < 2; ++q) {
+            if (bjH[q].n < pp) MMW_TRY(bjH[q].alloc(pp));
+            if (bjQ[q].n < pp) MMW_TRY(bjQ[q].alloc(pp));
+        }
+        if (bjR.n < (size_t)(M / 2) * BJ_N2 * BJ_N2) MMW_TRY(bjR.alloc((size_t)(M / 2) * BJ_N2 * BJ_N2));
+        static bool attr = false;
+        if (!attr) {
+            MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bj_apply), hipFuncAttributeMaxDynamicSharedMemorySize, BJ_APPLY_LDS));
+            attr = true;
+        }
+        static const bool all_full = getenv("MMW_BJ_FULL") != nullptr;  // every meeting solves the whole 64 x 64 problem
+        hipLaunchKernelGGL(k_bj_pad, dim3(grid_elems(pp)), dim3(BLOCK), 0, st, b, P, G.p, bjH[0].p, bjQ[0].p);
+        int cur = 0, sw = 0;
+        double h_off[2] = {0, 0};
+        const int half = M / 2;
+        for (; sw < max_sweeps; ++sw) {
+            hipLaunchKernelGGL(k_offdiag, dim3(1), dim3(1024), 0, st, P, bjH[cur].p, off.p);
+            MMW_HIP(hipMemcpyAsync(h_off, off.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+            MMW_HIP(hipStreamSynchronize(st));
+            if (!(std::sqrt(h_off[0]) > rel_tol * h_off[1] * std::sqrt((double)b)) || b < 2) break;
+            for (int r = 0; r < M - 1; ++r) {
+                hipLaunchKernelGGL(k_bj_solve, dim3(half), dim3(1024), 0, st, M, P, r, (r == 0 || all_full) ? 1 : 0, bjH[cur].p, bjR.p);
+                hipLaunchKernelGGL(k_bj_apply, dim3(half * half + (P / BJ_N2) * half), dim3(BLOCK), BJ_APPLY_LDS, st, M, P, r, bjH[cur].p,
+                                   bjH[cur ^ 1].p, bjQ[cur].p, bjQ[cur ^ 1].p, bjR.p);
+                cur ^= 1;
+            }
+            MMW_HIP(hipGetLastError());
+        }
+        if (sweeps_done) *sweeps_done = sw;
+        sweeps_total += sw;
+        calls_total += 1;
+        hipLaunchKernelGGL(k_bj_unpad, dim3(grid_elems((size_t)b * b)), dim3(BLOCK), 0, st, b, P, bjH[cur].p, bjQ[cur].p, diag.p, Q.p);
+        MMW_HIP(hipGetLastError());
+        return MMW_OK;
+    }
     int jacobi(int b, double rel_tol, int max_sweeps, int* sweeps_done = nullptr) {
+        static const bool blocked = getenv("MMW_JACOBI_ROUNDS") == nullptr;
+        if (blocked) return jacobi_blocked(b, rel_tol, max_sweeps, sweeps_done);
         const int n = (b % 2 == 0) ? b : b + 1;
         if (b <= JAC_LDS_MAX) {  // small: the whole eigensolve in one launch, matrices in LDS
             const size_t sh = ((size_t)2 * b * b + n + 2) * sizeof(double);
@@ -130,7 +174,7 @@ template <typename T> struct DenseWork {
         double* Qn = Q3.p;
         int sw = 0;
         for (; sw < max_sweeps; ++sw) {
-            hipLaunchKernelGGL(k_offdiag, dim3(1), dim3(BLOCK), 0, st, b, Hc, off.p);
+            hipLaunchKernelGGL(k_offdiag, dim3(1), dim3(1024), 0, st, b, Hc, off.p);
             MMW_HIP(hipMemcpyAsync(h_off, off.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
             MMW_HIP(hipStreamSynchronize(st));
             if (!(std::sqrt(h_off[0]) > rel_tol * h_off[1] * std::sqrt((double)b)) || b < 2) break;

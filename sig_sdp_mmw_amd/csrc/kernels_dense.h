@@ -272,6 +272,167 @@ __global__ __launch_bounds__(1024) void k_jacobi_lds(int b, const double* __rest
     for (int i = threadIdx.x; i < b; i += blockDim.x) diag[i] = H[i * b + i];
     if (threadIdx.x == 0 && sweeps_out) *sweeps_out = sw;
 }
+// ---- block Jacobi: the eigensolve above one round per launch (b - 1 launches a sweep, each a few microseconds of work) is
+// launch-bound.  Here the matrix is cut into 32-wide block columns (M of them, M even, zero-padded to P = 32 M); a block round
+// pairs them up disjointly (the same round-robin order, on blocks), and per round two launches do the work of ~63 element
+// rounds: k_bj_solve runs a cyclic Jacobi sweep on every pair's 64 x 64 diagonal problem in LDS (rotations as in
+// k_jacobi_lds) and leaves the accumulated 64 x 64 orthogonal factor R_a per pair; k_bj_apply forms H <- R^T H R and Q <- Q R
+// from the untouched input (ping-pong buffers), one workgroup per pair of pairs / per 64 rows of Q.  M - 1 block rounds make a
+// block sweep: every element pair has then been rotated at least once.  Padding rows are zero, so no rotation touches them.
+constexpr int BJ_NB = 32, BJ_N2 = 64;
+__global__ __launch_bounds__(BLOCK) void k_bj_pad(int b, int P, const double* __restrict__ G, double* __restrict__ Hp, double* __restrict__ Qp) {
+    for (int o = blockIdx.x * BLOCK + threadIdx.x; o < P * P; o += gridDim.x * BLOCK) {
+        const int i = o / P, j = o % P;
+        Hp[o] = (i < b && j < b) ? G[(size_t)i * b + j] : 0.0;
+        Qp[o] = i == j ? 1.0 : 0.0;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_bj_unpad(int b, int P, const double* __restrict__ Hp, const double* __restrict__ Qp,
+                                                    double* __restrict__ diag, double* __restrict__ Q) {
+    for (int o = blockIdx.x * BLOCK + threadIdx.x; o < b * b; o += gridDim.x * BLOCK) {
+        const int i = o / b, j = o % b;
+        Q[o] = Qp[(size_t)i * P + j];
+        if (i == j) diag[i] = Hp[(size_t)i * P + i];
+    }
+}
+__device__ __forceinline__ int bj_index(int I, int J, int k) { return k < BJ_NB ? BJ_NB * I + k : BJ_NB * J + (k - BJ_NB); }
+// 1024 threads: thread (i, j) owns the 2 x 2 quad of S that rotation pairs i and j meet in, and two rows of Qm for pair j.
+// `full` (the sweep's first block round): all 63 rounds of the 64-index tournament, so the pairs inside a block column are
+// rotated once per sweep too; otherwise only the 32 rounds that pair an index of block I with one of block J -- the pairs this
+// meeting exists for.  The rotation angle comes from a single-precision tangent (its exact value only decides how much of S_pq
+// is left for the next meeting); c and s are then formed in double, so every rotation is orthogonal to rounding.
+__device__ __forceinline__ void bj_pair(bool full, int rr, int i, int& p, int& q) {
+    if (full) jacobi_pair(BJ_N2, rr, i, p, q);
+    else { p = i; q = BJ_NB + ((i + rr) & (BJ_NB - 1)); }
+}
+__global__ __launch_bounds__(1024) void k_bj_solve(int M, int P, int r, int full, const double* __restrict__ Hin, double* __restrict__ R /* [M/2][64][64] */) {
+    __shared__ double S[BJ_N2][BJ_N2 + 1], Qm[BJ_N2][BJ_N2 + 1], cs[BJ_N2];
+    int I, J;
+    jacobi_pair(M, r, (int)blockIdx.x, I, J);
+    for (int o = threadIdx.x; o < BJ_N2 * BJ_N2; o += 1024) {
+        const int k = o >> 6, l = o & 63;
+        S[k][l] = Hin[(size_t)bj_index(I, J, k) * P + bj_index(I, J, l)];
+        Qm[k][l] = k == l ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    const int i = threadIdx.x >> 5, j = threadIdx.x & 31;
+    const int nrounds = full ? BJ_N2 - 1 : BJ_NB;
+    for (int rr = 0; rr < nrounds; ++rr) {
+        if (threadIdx.x < BJ_N2 / 2) {
+            int p, q;
+            bj_pair(full != 0, rr, (int)threadIdx.x, p, q);
+            double c = 1.0, sn = 0.0;
+            const float den = 2.f * (float)S[p][q];
+            if (den != 0.f) {
+                const float tau = (float)(S[q][q] - S[p][p]) / den;  // +-inf when S_pq is negligible: the tangent is then 0
+                const float tf = (tau >= 0.f ? 1.f : -1.f) / (fabsf(tau) + sqrtf(1.f + tau * tau));
+                const double t = (double)tf;
+                c = 1.0 / sqrt(1.0 + t * t);
+                sn = t * c;
+            }
+            cs[2 * threadIdx.x] = c;
+            cs[2 * threadIdx.x + 1] = sn;
+        }
+        __syncthreads();
+        int pi, qi, pj, qj;
+        bj_pair(full != 0, rr, i, pi, qi);
+        bj_pair(full != 0, rr, j, pj, qj);
+        const double ci = cs[2 * i], si = cs[2 * i + 1], cj = cs[2 * j], sj = cs[2 * j + 1];
+        {
+            const double h00 = S[pi][pj], h01 = S[pi][qj], h10 = S[qi][pj], h11 = S[qi][qj];
+            const double t00 = ci * h00 - si * h10, t01 = ci * h01 - si * h11;
+            const double t10 = si * h00 + ci * h10, t11 = si * h01 + ci * h11;
+            S[pi][pj] = t00 * cj - t01 * sj;
+            S[pi][qj] = t00 * sj + t01 * cj;
+            S[qi][pj] = t10 * cj - t11 * sj;
+            S[qi][qj] = t10 * sj + t11 * cj;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {  // Q <- Q J: row x = i + 32 h, column pair j
+            const int x = i + 32 * h;
+            const double a = Qm[x][pj], d = Qm[x][qj];
+            Qm[x][pj] = a * cj - d * sj;
+            Qm[x][qj] = a * sj + d * cj;
+        }
+        __syncthreads();
+    }
+    double* out = R + (size_t)blockIdx.x * BJ_N2 * BJ_N2;
+    for (int o = threadIdx.x; o < BJ_N2 * BJ_N2; o += 1024) out[o] = Qm[o >> 6][o & 63];
+}
+// H part: workgroup (a, c) of the (M/2)^2 pairs of pairs: Hout[A, C] = R_a^T Hin[A, C] R_c.  Q part: workgroup (x, c):
+// Qout[64 x .. 64 x + 63, C] = Qin[same rows, C] R_c.  256 threads, a 4 x 4 micro-tile each.
+__global__ __launch_bounds__(BLOCK) void k_bj_apply(int M, int P, int r, const double* __restrict__ Hin, double* __restrict__ Hout,
+                                                    const double* __restrict__ Qin, double* __restrict__ Qout, const double* __restrict__ R) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    typedef double Tile[BJ_N2][BJ_N2 + 1];
+    Tile& T = *reinterpret_cast<Tile*>(smem_raw);
+    Tile& Ra = *reinterpret_cast<Tile*>(smem_raw + sizeof(Tile));
+    Tile& Rc = *reinterpret_cast<Tile*>(smem_raw + 2 * sizeof(Tile));
+    const int half = M / 2;
+    const int nh = half * half;
+    const bool qpart = (int)blockIdx.x >= nh;
+    int a = 0, c, x = 0;
+    if (!qpart) { a = (int)blockIdx.x / half; c = (int)blockIdx.x % half; }
+    else { x = ((int)blockIdx.x - nh) / half; c = ((int)blockIdx.x - nh) % half; }
+    int Ia = 0, Ja = 0, Ic, Jc;
+    jacobi_pair(M, r, c, Ic, Jc);
+    if (!qpart) jacobi_pair(M, r, a, Ia, Ja);
+    const double* src = qpart ? Qin : Hin;
+    for (int o = threadIdx.x; o < BJ_N2 * BJ_N2; o += BLOCK) {
+        const int k = o >> 6, l = o & 63;
+        const int gr = qpart ? BJ_N2 * x + k : bj_index(Ia, Ja, k);
+        T[k][l] = src[(size_t)gr * P + bj_index(Ic, Jc, l)];
+        Rc[k][l] = R[(size_t)c * BJ_N2 * BJ_N2 + o];
+        if (!qpart) Ra[k][l] = R[(size_t)a * BJ_N2 * BJ_N2 + o];
+    }
+    __syncthreads();
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    double acc[4][4];
+    if (!qpart) {  // tmp = Ra^T T, written back over T
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+        for (int k = 0; k < BJ_N2; ++k) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { av[u] = Ra[k][4 * ty + u]; bv[u] = T[k][4 * tx + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] += av[u] * bv[v];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) T[4 * ty + u][4 * tx + v] = acc[u][v];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+    for (int k = 0; k < BJ_N2; ++k) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { av[u] = T[4 * ty + u][k]; bv[u] = Rc[k][4 * tx + u]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[u][v] += av[u] * bv[v];
+    }
+    double* dst = qpart ? Qout : Hout;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k = 4 * ty + u;
+        const int gr = qpart ? BJ_N2 * x + k : bj_index(Ia, Ja, k);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) dst[(size_t)gr * P + bj_index(Ic, Jc, 4 * tx + v)] = acc[u][v];
+    }
+}
+constexpr int BJ_APPLY_LDS = 3 * BJ_N2 * (BJ_N2 + 1) * (int)sizeof(double);
+
 // ---- Cholesky G = L L^T in place (lower triangle), right-looking in panels of 32 columns; *flag = 1 when a pivot is not
 // positive.  Per panel two launches: k_chol_panel factors the 32 x 32 diagonal block in LDS (every workgroup redundantly --
 // it is 3 us of work) and solves its slice of the rows below against it, one thread per row; k_chol_update subtracts the
@@ -393,20 +554,26 @@ __global__ __launch_bounds__(BLOCK) void k_trsm_rows(int K, int b, int ld, const
     }
 }
 // off-diagonal Frobenius norm^2 and diagonal scale: out[0] = sum_{i != j} H_ij^2, out[1] = max |H_ii|
-__global__ __launch_bounds__(BLOCK) void k_offdiag(int b, const double* __restrict__ H, double* __restrict__ out) {
-    __shared__ double sh[WAVES_PER_BLOCK];
+__global__ __launch_bounds__(1024) void k_offdiag(int b, const double* __restrict__ H, double* __restrict__ out) {
+    __shared__ double sh[2][16];
     double s = 0.0, d = 0.0;
-    for (int o = threadIdx.x; o < b * b; o += BLOCK) {
-        const int i = o / b, j = o % b;
-        const double h = H[o];
-        if (i != j) s += h * h;
-        else d = fabs(h) > d ? fabs(h) : d;
+    for (int i = threadIdx.x >> 6; i < b; i += 16) {  // a wave per row: coalesced, no division
+        const double* row = H + (size_t)i * b;
+        for (int j = threadIdx.x & 63; j < b; j += WAVE) {
+            const double h = row[j];
+            if (i != j) s += h * h;
+            else d = fabs(h) > d ? fabs(h) : d;
+        }
     }
-    s = block_sum(s, sh);
-    d = block_max(d, sh);
+    s = wave_sum(s);
+    d = wave_max(d);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = d; }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        out[0] = s;
-        out[1] = d;
+        double ts = 0.0, td = 0.0;
+        for (int w = 0; w < 16; ++w) { ts += sh[0][w]; td = sh[1][w] > td ? sh[1][w] : td; }
+        out[0] = ts;
+        out[1] = td;
     }
 }
 __global__ __launch_bounds__(BLOCK) void k_set_eye(int b, double* __restrict__ Q) {
