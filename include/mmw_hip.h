@@ -169,6 +169,14 @@ int mmw_expm_apply(int device, int dtype, int method, int max_order, double tol,
                    double* out, double info[4], int32_t reps, double* kernel_us);
 
 /*
+ * mmw_sym_eig: the dense symmetric eigensolve inside mmw_factor's Rayleigh-Ritz step, stand-alone (the reference gets it from
+ * LAPACK inside scipy.sparse.linalg.eigsh / svds, mmw.py:206-212): G = Q diag(theta) Q^T for a symmetric b x b matrix (row-major
+ * float64) by block Jacobi on the device.  Stops when the off-diagonal Frobenius norm is below rel_tol * max|diag| * sqrt(b)
+ * or after max_sweeps block sweeps (*sweeps, may be NULL, receives the count).  theta is not sorted.
+ */
+int mmw_sym_eig(int device, int32_t b, const double* G, double rel_tol, int32_t max_sweeps, double* theta, double* Q, int32_t* sweeps);
+
+/*
  * mmw_round: one sdp_solver.rounding_one_attempt (sdp_solver.py:27-107) per projection batch entry.
  * gX[K,Dp] and randv[nbatch,Z,Dp] (row-normalised, sdp_solver.py:48-49) in float64.  For every batch
  * entry: inprod = randv gX^T on the fp64 matrix cores, per-user slot preference order, the greedy

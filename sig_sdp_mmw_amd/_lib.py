@@ -22,7 +22,7 @@ I_L_INDPTR, I_L_INDICES, I_ST_INDPTR, I_ST_INDICES, I_GAIN_X, I_GAIN_Y, I_ASSO_X
 
 EXPORTS = ["mmw_last_error", "mmw_version", "mmw_device_count", "mmw_create", "mmw_destroy", "mmw_sizes", "mmw_set_expm",
            "mmw_set_timing", "mmw_set_profile", "mmw_bench_spmm", "mmw_reset", "mmw_set_slots", "mmw_set_slots_warm", "mmw_set_eta", "mmw_iterate", "mmw_sync", "mmw_read_f64", "mmw_read_i32", "mmw_gap",
-           "mmw_factor", "mmw_expm_apply", "mmw_round", "mmw_env_create", "mmw_env_destroy", "mmw_env_sizes", "mmw_env_state",
+           "mmw_factor", "mmw_expm_apply", "mmw_sym_eig", "mmw_round", "mmw_env_create", "mmw_env_destroy", "mmw_env_sizes", "mmw_env_state",
            "mmw_env_evaluate"]
 
 
@@ -66,6 +66,7 @@ def lib():
     L.mmw_read_i32.argtypes = [C.c_void_p, C.c_int, p_i32, C.c_int64]
     L.mmw_gap.argtypes = [C.c_void_p, p_f64]
     L.mmw_factor.argtypes = [C.c_void_p, C.c_int32, p_f64, C.c_uint64]
+    L.mmw_sym_eig.argtypes = [C.c_int, C.c_int32, p_f64, C.c_double, C.c_int32, p_f64, p_f64, C.POINTER(C.c_int32)]
     L.mmw_expm_apply.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int32, C.c_int32, p_i32, p_i32, p_f64,
                                  p_f64, p_f64, p_f64, C.c_int32, p_f64]
     L.mmw_round.argtypes = [C.c_void_p, C.c_int32, C.c_int32, p_f64, C.c_int32, p_f64, p_i32, p_i32]
@@ -328,6 +329,19 @@ class DeviceEnv:
             self.close()
         except Exception:
             pass
+
+
+def sym_eig(G, rel_tol=1e-13, max_sweeps=30, device=0):
+    """Eigen-decomposition of a symmetric matrix by the device's block Jacobi; returns (theta unsorted, Q, block sweeps)."""
+    G = _f64(G)
+    b = G.shape[0]
+    if G.shape != (b, b):
+        raise ValueError("sym_eig: square matrix expected")
+    theta = np.empty(b, dtype=np.float64)
+    Q = np.empty((b, b), dtype=np.float64)
+    sw = C.c_int32(0)
+    check(lib().mmw_sym_eig(int(device), b, _pd(G), float(rel_tol), int(max_sweeps), _pd(theta), _pd(Q), C.byref(sw)))
+    return theta, Q, sw.value
 
 
 def expm_apply(A_csr, B, dtype=F64, method=EXPM_LANCZOS, max_order=12, tol=1e-9, device=0, reps=1):

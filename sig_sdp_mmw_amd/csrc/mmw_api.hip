@@ -1175,6 +1175,32 @@ int mmw_expm_apply(int device, int dtype, int method, int max_order, double tol,
 }
 
 
+int mmw_sym_eig(int device, int32_t b, const double* G, double rel_tol, int32_t max_sweeps, double* theta, double* Q, int32_t* sweeps) {
+    if (!G || !theta || !Q) return fail(MMW_ERR_ARG, "mmw_sym_eig: null pointer");
+    if (b < 1 || b > 2048) return fail(MMW_ERR_ARG, "mmw_sym_eig: b must be in [1, 2048]");
+    if (!(rel_tol > 0.0) || max_sweeps < 1) return fail(MMW_ERR_ARG, "mmw_sym_eig: rel_tol and max_sweeps must be positive");
+    int ndev = 0;
+    MMW_TRY(mmw_device_count(&ndev));
+    if (device < 0 || device >= ndev) return fail(MMW_ERR_HIP, "mmw_sym_eig: no such HIP device");
+    MMW_HIP(hipSetDevice(device));
+    struct Stream {
+        hipStream_t s = nullptr;
+        ~Stream() { if (s) (void)hipStreamDestroy(s); }
+    } stream;
+    MMW_HIP(hipStreamCreate(&stream.s));
+    mmw::DenseWork<double> dw;
+    dw.st = stream.s;
+    MMW_TRY(dw.ensure(b, 1));
+    MMW_HIP(hipMemcpyAsync(dw.G.p, G, (size_t)b * b * sizeof(double), hipMemcpyHostToDevice, stream.s));
+    int sw = 0;
+    MMW_TRY(dw.jacobi(b, rel_tol, max_sweeps, &sw));
+    MMW_HIP(hipMemcpyAsync(theta, dw.diag.p, (size_t)b * sizeof(double), hipMemcpyDeviceToHost, stream.s));
+    MMW_HIP(hipMemcpyAsync(Q, dw.Q.p, (size_t)b * b * sizeof(double), hipMemcpyDeviceToHost, stream.s));
+    MMW_HIP(hipStreamSynchronize(stream.s));
+    if (sweeps) *sweeps = sw;
+    return MMW_OK;
+}
+
 // ---- problem generator and scorer on the device (include/mmw_hip.h) ----------------------------------------
 struct mmw_env {
     mmw::EnvDevice e;

@@ -164,3 +164,39 @@ def test_replayed_chunks_keep_the_phase_timers_consistent(monkeypatch):
     info = s.read(_lib.F_BLOCKING)
     assert info[3] >= 1, "this configuration is expected to replay at least one chunk"
     s.close()
+
+
+def _sym(b, kind, rng):
+    if kind == "random":
+        A = rng.standard_normal((b, b))
+        return (A + A.T) / 2
+    if kind == "gram":  # what the Rayleigh-Ritz step sees: nearly diagonal, decaying spectrum
+        Qr, _ = np.linalg.qr(rng.standard_normal((b, b)))
+        lam = np.exp(-np.arange(b) / (b / 8.0)) * np.where(rng.random(b) < 0.3, -1.0, 1.0)
+        return (Qr * lam) @ Qr.T * 0.02 + np.diag(lam)
+    if kind == "clustered":  # repeated eigenvalues: any basis of the eigenspace is right
+        Qr, _ = np.linalg.qr(rng.standard_normal((b, b)))
+        lam = np.repeat([3.0, 3.0, -1.0, 0.5], (b + 3) // 4)[:b]
+        return (Qr * lam) @ Qr.T
+    if kind == "diagonal":
+        return np.diag(rng.standard_normal(b))
+    return np.zeros((b, b))
+
+
+@pytest.mark.parametrize("b", [1, 2, 31, 64, 65, 100, 250, 444])
+@pytest.mark.parametrize("kind", ["random", "gram", "clustered", "diagonal", "zero"])
+def test_sym_eig_matches_lapack(b, kind):
+    """The Rayleigh-Ritz eigensolve (block Jacobi, kernels_dense.h) against numpy.linalg.eigh: eigenvalues, orthogonality and
+    the decomposition itself, at the sizes the factor uses it (one block pair ... 14 block columns, odd block counts padded)."""
+    rng = np.random.default_rng(b * 7 + len(kind))
+    G = _sym(b, kind, rng)
+    # repeated eigenvalues slow this ordering of rotations down to a linear rate (the one-launch-per-round solver it replaces
+    # needs 20-28 sweeps on the same matrices): more room there; the Rayleigh-Ritz matrices ("gram") take 6-8
+    limit = 80 if kind == "clustered" else 30
+    theta, Q, sweeps = _lib.sym_eig(G, 1e-13, limit)
+    assert sweeps < limit
+    ref = np.linalg.eigvalsh(G)
+    scale = max(1.0, np.abs(ref).max())
+    assert np.abs(np.sort(theta) - ref).max() < 1e-11 * scale * max(1, b) ** 0.5
+    assert np.abs(Q.T @ Q - np.eye(b)).max() < 1e-12 * max(1, b) ** 0.5
+    assert np.abs(G @ Q - Q * theta).max() < 1e-11 * scale * max(1, b) ** 0.5
