@@ -132,7 +132,8 @@ inline unsigned long long* g_mf_stamps = nullptr;  // diagnostic runs only: per-
 // the block's A fragments once per group).
 template <int MODE>
 inline int spmm_mfma_launch(hipStream_t st, const MfmaDev& M, int mt, int Dpad, size_t plane_bytes, const char* planes, const float* in,
-                            float* out, double ascale, double shift, double* partial, double* partial_o2, const ExpmPlan* plan, int step, int* viol) {
+                            float* out, double ascale, double shift, double* partial, double* partial_o2, const ExpmPlan* plan, int step, int* viol,
+                            MfEpi epi = MfEpi{}) {
     const int ntiles = Dpad / 32;
     const int grid_x = (M.nb + 7) / 8 * 8;
     static int cus = 0;
@@ -153,7 +154,7 @@ inline int spmm_mfma_launch(hipStream_t st, const MfmaDev& M, int mt, int Dpad, 
         }                                                                                                                              \
         hipLaunchKernelGGL((k_spmm_mfma<MODE, MT, NT, NW, MS, KC, NB>), dim3(grid_x, (ntiles + gtw - 1) / gtw), dim3(NW * 64),         \
                            lds_bytes, st, M, Dpad, plane_bytes, planes, in, out, ascale, shift, partial, partial_o2,                   \
-                           plan, step, viol, g_mf_stamps);                                                                             \
+                           plan, step, viol, g_mf_stamps, epi);                                                                        \
     } while (0)
     int gt = 12;  // column tiles per workgroup: 12, 8 or 4
     static const int gt_env = getenv("MMW_MF_GT") ? atoi(getenv("MMW_MF_GT")) : 0;

@@ -250,11 +250,45 @@ template <typename T> struct Factorizer {
     void set_blocking(const BlkDev& b, const int* blocked_to_csr, int64_t entries) {
         blk = b; bepos = blocked_to_csr; nent = entries; have_blk = true;
     }
+    // optional matrix-core blocking (fp32): the Chebyshev filter's products run on k_spmm_mfma while the block is still far
+    // from converged (see run()); the matrix goes once per call into a fragment image of its own
+    bool have_mf = false;
+    MfmaDev mf{};
+    int mf_mt = 1;
+    const int* mf_fpos = nullptr;
+    size_t mf_image = 0;
+    int64_t mf_nnz = 0;
+    DevBuf<unsigned> afrag;
+    void set_mfma(const MfmaDev& m, int mt, const int* fpos, size_t image_words, int64_t nnz) {
+        mf = m; mf_mt = mt; mf_fpos = fpos; mf_image = image_words; mf_nnz = nnz; have_mf = true;
+    }
     template <int MODE>
     int spmm(const BlockLayout& lay, int nblk, const int* indptr, const int* col, const T* val, const T* in, T* outp, T* Fp, const T* X2p,
              double c1, double c2, double c3) {
         if (have_blk) return spmm_blk_launch<T, MODE>(st, blk, lay.Dpad, val_blk.p, in, outp, Fp, X2p, c1, c2, c3, nullptr);
         return spmm_launch<T, MODE>(st, K, lay, nblk, indptr, col, val, in, outp, Fp, X2p, c1, c2, c3, nullptr);
+    }
+
+    // the matrix-core form of the two products above (fp32 only): `in` is read through its planes, the result is written with its own
+    size_t mf_bs = 0;  // K * ld of the running call
+    unsigned short* planes_of(T* block) const { return reinterpret_cast<unsigned short*>(block + mf_bs); }
+    int split(T* block) {
+        if constexpr (sizeof(T) == 4) {
+            hipLaunchKernelGGL(k_split_planes, dim3(grid_elems(mf_bs / 4)), dim3(BLOCK), 0, st, mf_bs / 4, reinterpret_cast<const float4*>(block),
+                               reinterpret_cast<uint2*>(planes_of(block)), reinterpret_cast<uint2*>(planes_of(block) + mf_bs));
+            MMW_HIP(hipGetLastError());
+        }
+        return MMW_OK;
+    }
+    template <int MODE>
+    int spmm_mf(int ld, T* in, T* outp, const T* Fp, const T* X2p, double c1, double c2, double c3) {
+        if constexpr (sizeof(T) == 4) {
+            MfEpi e;
+            e.F = Fp; e.X2 = X2p; e.c3 = (float)c3; e.out_planes = planes_of(outp);
+            return spmm_mfma_launch<MODE>(st, mf, mf_mt, ld, mf_bs * sizeof(unsigned short), reinterpret_cast<const char*>(planes_of(in)), in, outp, c1, c2,
+                                          nullptr, nullptr, nullptr, 0, nullptr, e);
+        }
+        return fail(MMW_ERR_STATE, "matrix-core products are fp32 only");
     }
 
     // V <- V * F twice with F from the Gram matrix: Cholesky-QR (cheap) and, when the block is too
@@ -296,7 +330,12 @@ template <typename T> struct Factorizer {
         const int ld = lay.Dpad;
         const size_t bs = (size_t)K * ld;
         const int nblk = grid_slabs(K);
-        if (V.n < bs) { MMW_TRY(V.alloc(bs)); MMW_TRY(W.alloc(bs)); MMW_TRY(Y1.alloc(bs)); MMW_TRY(Y2.alloc(bs)); }
+        // matrix-core filter passes: every block carries its bf16 hi / lo planes right behind its fp32 values
+        bool mf_use = false;
+        if constexpr (sizeof(T) == 4) mf_use = have_mf && have_blk && b < K && ld % 32 == 0 && !getenv("MMW_FACTOR_NO_MFMA");
+        const size_t bs_alloc = mf_use ? 2 * bs : bs;
+        mf_bs = bs;
+        if (V.n < bs_alloc) { MMW_TRY(V.alloc(bs_alloc)); MMW_TRY(W.alloc(bs_alloc)); MMW_TRY(Y1.alloc(bs_alloc)); MMW_TRY(Y2.alloc(bs_alloc)); }
         if (partial.n < (size_t)MAX_PART * ld) MMW_TRY(partial.alloc((size_t)MAX_PART * ld));
         if (colsum.n < (size_t)ld) MMW_TRY(colsum.alloc(ld));
         if (rho_part.n < (size_t)MAX_PART) MMW_TRY(rho_part.alloc(MAX_PART));
@@ -305,6 +344,14 @@ template <typename T> struct Factorizer {
         if (have_blk) {  // matrix values once into the blocked order (padding entries stay zero)
             if (val_blk.n < (size_t)nent) MMW_TRY(val_blk.alloc((size_t)nent));
             hipLaunchKernelGGL((k_gather_blocked<T>), dim3(grid_elems((size_t)nent)), dim3(BLOCK), 0, st, (size_t)nent, bepos, val, val_blk.p);
+        }
+        if constexpr (sizeof(T) == 4) {
+            if (mf_use) {
+                if (afrag.n < mf_image) MMW_TRY(afrag.alloc(mf_image));
+                MMW_HIP(hipMemsetAsync(afrag.p, 0, mf_image * sizeof(unsigned), st));
+                hipLaunchKernelGGL((k_refrag<T>), dim3(grid_elems((size_t)mf_nnz)), dim3(BLOCK), 0, st, (size_t)mf_nnz, val, mf_fpos, afrag.p);
+                mf.afrag = afrag.p;
+            }
         }
         // spectral scale: ||A||_1 >= |lambda|_max
         hipLaunchKernelGGL((k_rowabs<T>), dim3(nblk), dim3(BLOCK), 0, st, K, indptr, col, val, ascale, (const double*)nullptr, 0, rho_part.p);
@@ -327,7 +374,16 @@ template <typename T> struct Factorizer {
         int rr_skip = 0;  // filter passes still to run before the next Rayleigh-Ritz
         bool skip_rr = false;
         for (; outer < max_outer && !done; ++outer) {
+            // Matrix-core products (two-half bf16 split, error <= 2.3e-5 || |A| || per product) serve the filter while the last
+            // residual says that at least two more passes follow: the subspace error they leave is far below what those passes
+            // start from, and every Rayleigh-Ritz product and the last passes run on the fp32 kernel.
+            const bool mf_stage = mf_use && (outer == 0 || last_resid > 100.0 * tol);
+            const bool no_rr_next = rr_skip > 0 && b < K;
             // ---- Rayleigh-Ritz on span(V)
+            if (mf_stage && no_rr_next) {  // this product only feeds the filter
+                MMW_TRY(split(V.p));
+                MMW_TRY((spmm_mf<SPMM_PLAIN>(ld, V.p, W.p, nullptr, nullptr, ascale, 0.0, 0.0)));
+            } else
             MMW_TRY((spmm<SPMM_PLAIN>(lay, nblk, indptr, col, val, V.p, W.p, nullptr, nullptr, ascale, 0.0, 0.0)));
             // The Rayleigh-Ritz step (Gram matrix, dense eigensolve, two tall GEMMs, residuals) only rotates the basis and tells how
             // far it is: the filter works on the subspace whatever its basis.  While the last residual says that more than one
@@ -393,6 +449,11 @@ template <typename T> struct Factorizer {
             const double a0 = skip_rr ? rho * rho : std::max(mu_top, rho * rho * 1e-30);  // no Ritz values yet: the 1-norm bounds the spectrum
             double sigma1 = e / (a0 - cen), sigma = sigma1;
             // Y = sigma1/e (B V - cen V): T1 = A V (already W); Ycur = c1 * A W + c2 * V
+            const bool mf_pass = mf_stage && (no_rr || last_resid > 100.0 * tol || skip_rr);  // this pass's residual is known by now
+            if (mf_pass) {
+                if (!(mf_stage && no_rr)) MMW_TRY(split(W.p));  // W came from the fp32 kernel (or was rotated by the Rayleigh-Ritz step)
+                MMW_TRY((spmm_mf<SPMM_AXPBY>(ld, W.p, Y1.p, V.p, V.p, ascale * sigma1 / e, -cen * sigma1 / e, 0.0)));
+            } else
             MMW_TRY((spmm<SPMM_AXPBY>(lay, nblk, indptr, col, val, W.p, Y1.p, V.p, V.p, ascale * sigma1 / e, -cen * sigma1 / e, 0.0)));
             // V = previous, Y1 = current
             T* prev = V.p;
@@ -400,10 +461,15 @@ template <typename T> struct Factorizer {
             T* nxt = Y2.p;
             for (int i = 2; i <= degree; ++i) {
                 const double sigma2 = 1.0 / (2.0 / sigma1 - sigma);
-                MMW_TRY((spmm<SPMM_PLAIN>(lay, nblk, indptr, col, val, cur, W.p, nullptr, nullptr, ascale, 0.0, 0.0)));
                 // nxt = 2 sigma2/e (A W - cen cur) - sigma sigma2 prev
+                if (mf_pass) {
+                    MMW_TRY((spmm_mf<SPMM_PLAIN>(ld, cur, W.p, nullptr, nullptr, ascale, 0.0, 0.0)));
+                    MMW_TRY((spmm_mf<SPMM_AXPBY>(ld, W.p, nxt, cur, prev, ascale * 2.0 * sigma2 / e, -cen * 2.0 * sigma2 / e, -sigma * sigma2)));
+                } else {
+                MMW_TRY((spmm<SPMM_PLAIN>(lay, nblk, indptr, col, val, cur, W.p, nullptr, nullptr, ascale, 0.0, 0.0)));
                 MMW_TRY((spmm<SPMM_AXPBY>(lay, nblk, indptr, col, val, W.p, nxt, cur, prev, ascale * 2.0 * sigma2 / e, -cen * 2.0 * sigma2 / e,
                                           -sigma * sigma2)));
+                }
                 T* t = prev;
                 prev = cur;
                 cur = nxt;

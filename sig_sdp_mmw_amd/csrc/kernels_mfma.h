@@ -70,6 +70,15 @@ struct MfmaDev {             // the matrix-core kernel's own row blocks (blockin
     const int* kbase;        // [nb+1] (padded) k-steps before each block
     const unsigned* afrag;   // fragment-ordered image of the matrix, hi << 16 | lo
 };
+// optional inputs / outputs of the epilogue: the AXPBY form (Out = ascale A U + shift F + c3 X2, the Chebyshev recurrences of
+// factor.h) reads F and X2 at the output rows; out_planes, when set, also receives the result as bf16 hi / lo planes (the next
+// product's B operand), hi plane first, the lo plane plane_bytes further
+struct MfEpi {
+    const float* F = nullptr;
+    const float* X2 = nullptr;
+    float c3 = 0.f;
+    unsigned short* out_planes = nullptr;
+};
 // a chunk = KC k-steps: per k-step the B image (2 planes x 16 rows x the group's columns), then the A fragments of all KC steps
 // GT = column tiles per workgroup
 template <int MT, int GT, int KC> constexpr int mf_chunk_bytes() { return KC * (2048 * GT + 2048 * MT); }
@@ -105,8 +114,8 @@ template <int MODE, int MT, int NT, int NW, int MS, int KC, int NB>
 __global__ __launch_bounds__(NW * 64)
 void k_spmm_mfma(MfmaDev M, int Dpad, size_t plane_bytes, const char* __restrict__ Upl, const float* __restrict__ U,
                  float* __restrict__ Out, double ascale_d, double shift_d, double* __restrict__ partial, double* __restrict__ partial_o2,
-                 const ExpmPlan* __restrict__ plan, int step, int* __restrict__ viol, unsigned long long* __restrict__ stamps) {
-    static_assert(MODE == SPMM_PLAIN || MODE == SPMM_LANCZOS, "the matrix-core SpMM has the plain and the Lanczos epilogue");
+                 const ExpmPlan* __restrict__ plan, int step, int* __restrict__ viol, unsigned long long* __restrict__ stamps, MfEpi E) {
+    static_assert(MODE == SPMM_PLAIN || MODE == SPMM_LANCZOS || MODE == SPMM_AXPBY, "the matrix-core SpMM has the plain, the Lanczos and the AXPBY epilogue");
     static_assert(MF_KPAD % KC == 0, "the fragment image pads a block's k-steps to whole chunks");
     // diagnostic runs only (stamps != nullptr): shader-clock sums per wave {prologue, wait + barrier, DMA issue, products, epilogue, steps}
     unsigned long long tk0 = 0, tk1 = 0, acc_wait = 0, acc_issue = 0, acc_comp = 0, t_pro = 0;
@@ -303,9 +312,17 @@ void k_spmm_mfma(MfmaDev M, int Dpad, size_t plane_bytes, const char* __restrict
             float u[16];
 #pragma unroll
             for (int v = 0; v < 16; ++v) rows[v] = orow_l[32 * (wm * MTW + m) + (v & 3) + 8 * (v >> 2) + 4 * h2];
+            float x2[16];
             if (MODE == SPMM_LANCZOS) {
 #pragma unroll
                 for (int v = 0; v < 16; ++v) u[v] = U[(size_t)max(rows[v], 0) * Dpad + col];
+            }
+            if (MODE == SPMM_AXPBY) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    u[v] = E.F[(size_t)max(rows[v], 0) * Dpad + col];
+                    x2[v] = E.X2[(size_t)max(rows[v], 0) * Dpad + col];
+                }
             }
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
@@ -316,10 +333,20 @@ void k_spmm_mfma(MfmaDev M, int Dpad, size_t plane_bytes, const char* __restrict
                         dot += u[v] * o;
                         dot2 += o * o;
                     }
+                } else if (MODE == SPMM_AXPBY) {
+                    o = ascale * acc[m][i][v] + shift * u[v] + E.c3 * x2[v];
                 } else {
                     o = ascale * acc[m][i][v];
                 }
-                if (rows[v] >= 0) Out[(size_t)rows[v] * Dpad + col] = o;
+                if (rows[v] >= 0) {
+                    const size_t at = (size_t)rows[v] * Dpad + col;
+                    Out[at] = o;
+                    if (MODE != SPMM_LANCZOS && E.out_planes) {
+                        const unsigned w = split_bf16(o);
+                        E.out_planes[at] = (unsigned short)(w >> 16);
+                        *reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(E.out_planes) + plane_bytes + at * 2) = (unsigned short)(w & 0xFFFFu);
+                    }
+                }
             }
         }
         if (MODE == SPMM_LANCZOS) {

@@ -321,6 +321,7 @@ template <typename T> struct Solver final : mmw_solver {
         }
         MMW_HIP(hipStreamSynchronize(st));
         extras.fac.set_blocking(blkdev(), b_bepos.p, HB.nent);
+        if (eng.use_mfma) extras.fac.set_mfma(eng.mf, HB.mfma_mt, b_fpos.p, afrag_n, (int64_t)H.nnzL());
         eng.blk_stale = &lblk_stale;
         eng.blk_refresh = [this]() -> int {
             hipLaunchKernelGGL((k_gather_blocked<T>), dim3(grid_elems((size_t)HB.nent)), dim3(BLOCK), 0, st, (size_t)HB.nent, b_bepos.p, lval.p, lval_blk.p);
