@@ -377,7 +377,8 @@ template <typename T> struct Factorizer {
             // Matrix-core products (two-half bf16 split, error <= 2.3e-5 || |A| || per product) serve the filter while the last
             // residual says that at least two more passes follow: the subspace error they leave is far below what those passes
             // start from, and every Rayleigh-Ritz product and the last passes run on the fp32 kernel.
-            const bool mf_stage = mf_use && (outer == 0 || last_resid > 100.0 * tol);
+            static const double mf_floor = getenv("MMW_FACTOR_MF_FLOOR") ? atof(getenv("MMW_FACTOR_MF_FLOOR")) : 100.0;
+            const bool mf_stage = mf_use && (outer == 0 || last_resid > mf_floor * tol);
             const bool no_rr_next = rr_skip > 0 && b < K;
             // ---- Rayleigh-Ritz on span(V)
             if (mf_stage && no_rr_next) {  // this product only feeds the filter
@@ -449,7 +450,7 @@ template <typename T> struct Factorizer {
             const double a0 = skip_rr ? rho * rho : std::max(mu_top, rho * rho * 1e-30);  // no Ritz values yet: the 1-norm bounds the spectrum
             double sigma1 = e / (a0 - cen), sigma = sigma1;
             // Y = sigma1/e (B V - cen V): T1 = A V (already W); Ycur = c1 * A W + c2 * V
-            const bool mf_pass = mf_stage && (no_rr || last_resid > 100.0 * tol || skip_rr);  // this pass's residual is known by now
+            const bool mf_pass = mf_stage && (no_rr || last_resid > mf_floor * tol || skip_rr);  // this pass's residual is known by now
             if (mf_pass) {
                 if (!(mf_stage && no_rr)) MMW_TRY(split(W.p));  // W came from the fp32 kernel (or was rotated by the Rayleigh-Ritz step)
                 MMW_TRY((spmm_mf<SPMM_AXPBY>(ld, W.p, Y1.p, V.p, V.p, ascale * sigma1 / e, -cen * sigma1 / e, 0.0)));
