@@ -45,6 +45,7 @@ struct HostBlocking {
     std::vector<uint16_t> sd_la, sd_lb; // local index of the row / of the column in the block's union
     std::vector<int32_t> sd_epos;       // original CSR position of the entry
     int sd_max = 0;                     // largest per-block entry count
+    bool sd_ready = false;              // sd_* / sd2_* below are built (build_sd_tables): only the LDS-staged SDDMM kernels read them
     // half-tile SDDMM (k_sddmm_blk2): the same entries dealt to thread slots, slot = round * 512 + thread.  The two
     // lanes of an LDS service group that read the same 16-byte chunk hold entries of complementary row parity (both
     // for the row side and the column side), so every read is bank-conflict free; -1 marks an idle slot.
@@ -280,13 +281,8 @@ inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& i
     // blocked nnz arrays
     B.bptr.assign(K + 1, 0);
     B.self_li.assign(K, 0);
-    B.sd_ptr.assign(1, 0);
-    B.sd2_ptr.assign(1, 0);
-    B.sd2_ab.clear(); B.sd2_epos.clear();
-    B.sd2_rounds = 0;
     B.un8_max = 0;
-    B.sd_la.clear(); B.sd_lb.clear(); B.sd_epos.clear();
-    B.sd_max = 0;
+    B.sd_ready = false;
     B.lidx.clear();
     B.bepos.clear();
     B.lidx.reserve(nnz + (int64_t)K * 2 * BLK_CHUNK);
@@ -331,6 +327,49 @@ inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& i
                     ++w;
                 }
             B.bptr[q + 1] = (int32_t)w;
+        }
+    }
+    B.nent = w;
+    B.desc.assign((size_t)B.nb() * 8, 0);
+    B.un_fixed.assign((size_t)B.nb() * BLK_UNION, 0);
+    for (int b = 0; b < B.nb(); ++b) {
+        const int q0 = B.blk_rowptr[b], q1 = B.blk_rowptr[b + 1];
+        const int nun = B.un_ptr[b + 1] - B.un_ptr[b];
+        int32_t* d = &B.desc[(size_t)b * 8];
+        d[0] = q0; d[1] = q1 - q0; d[2] = B.bptr[q0]; d[3] = B.bptr[q1] - B.bptr[q0]; d[4] = B.un_ptr[b]; d[5] = nun;
+        d[6] = (B.bptr[q1] - B.bptr[q0]) / BLK_CHUNK;
+        d[7] = 0;  // first slot of the half-tile SDDMM: build_sd_tables
+        B.un8_max = std::max(B.un8_max, (nun + 7) & ~7);
+        for (int u = 0; u < BLK_UNION; ++u) B.un_fixed[(size_t)b * BLK_UNION + u] = B.un_cols[B.un_ptr[b] + (u < nun ? u : 0)];
+    }
+    B.reuse = B.un_cols.empty() ? 0.0 : (double)nnz / (double)B.un_cols.size();
+    B.fits_half_tile = true;
+    bool fits_full = true;
+    for (int b = 0; b < B.nb(); ++b) {
+        const int32_t* d = &B.desc[(size_t)b * 8];
+        if (d[3] > max_entries_per_block) fits_full = false;
+        if (blk2_lds_need(d[5], d[3], lim.entry_bytes) > BLK2_LDS_BYTES) B.fits_half_tile = false;
+    }
+    B.usable = B.reuse >= 2.0 && fits_full;
+}
+
+// The entry tables of the LDS-staged SDDMM kernels (k_sddmm_blk, k_sddmm_blk2) for the blocks build_blocking made.  A third of
+// the blocking's host time, and dead weight for a handle whose SDDMM runs on the matrix cores: built on first need.
+inline void build_sd_tables(HostBlocking& B, int K, const std::vector<int32_t>& indptr, const std::vector<int32_t>& indices) {
+    if (B.sd_ready || !B.usable) return;
+    B.sd_ptr.assign(1, 0);
+    B.sd2_ptr.assign(1, 0);
+    B.sd2_ab.clear(); B.sd2_epos.clear();
+    B.sd2_rounds = 0;
+    B.sd_la.clear(); B.sd_lb.clear(); B.sd_epos.clear();
+    B.sd_max = 0;
+    std::vector<int32_t> local(K, -1);
+    for (int b = 0; b < B.nb(); ++b) {
+        if (b > 0)
+            for (int u = B.un_ptr[b - 1]; u < B.un_ptr[b]; ++u) local[B.un_cols[u]] = -1;
+        for (int u = B.un_ptr[b]; u < B.un_ptr[b + 1]; ++u) local[B.un_cols[u]] = u - B.un_ptr[b];
+        for (int q = B.blk_rowptr[b]; q < B.blk_rowptr[b + 1]; ++q) {
+            const int r = B.order[q];
             for (int e = indptr[r]; e < indptr[r + 1]; ++e)
                 if (indices[e] > r) {
                     B.sd_la.push_back((uint16_t)local[r]);
@@ -384,28 +423,8 @@ inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& i
             B.sd2_ptr.push_back((int32_t)B.sd2_ab.size());
         }
     }
-    B.nent = w;
-    B.desc.assign((size_t)B.nb() * 8, 0);
-    B.un_fixed.assign((size_t)B.nb() * BLK_UNION, 0);
-    for (int b = 0; b < B.nb(); ++b) {
-        const int q0 = B.blk_rowptr[b], q1 = B.blk_rowptr[b + 1];
-        const int nun = B.un_ptr[b + 1] - B.un_ptr[b];
-        int32_t* d = &B.desc[(size_t)b * 8];
-        d[0] = q0; d[1] = q1 - q0; d[2] = B.bptr[q0]; d[3] = B.bptr[q1] - B.bptr[q0]; d[4] = B.un_ptr[b]; d[5] = nun;
-        d[6] = (B.bptr[q1] - B.bptr[q0]) / BLK_CHUNK;
-        d[7] = B.sd2_ptr[b];
-        B.un8_max = std::max(B.un8_max, (nun + 7) & ~7);
-        for (int u = 0; u < BLK_UNION; ++u) B.un_fixed[(size_t)b * BLK_UNION + u] = B.un_cols[B.un_ptr[b] + (u < nun ? u : 0)];
-    }
-    B.reuse = B.un_cols.empty() ? 0.0 : (double)nnz / (double)B.un_cols.size();
-    B.fits_half_tile = true;
-    bool fits_full = true;
-    for (int b = 0; b < B.nb(); ++b) {
-        const int32_t* d = &B.desc[(size_t)b * 8];
-        if (d[3] > max_entries_per_block) fits_full = false;
-        if (blk2_lds_need(d[5], d[3], lim.entry_bytes) > BLK2_LDS_BYTES) B.fits_half_tile = false;
-    }
-    B.usable = B.reuse >= 2.0 && fits_full;
+    for (int b = 0; b < B.nb(); ++b) B.desc[(size_t)b * 8 + 7] = B.sd2_ptr[b];
+    B.sd_ready = true;
 }
 
 // Row blocks for the matrix-core SpMM (kernels_mfma.h): grown like the blocks above (seed = next unassigned row of the RCM

@@ -102,6 +102,7 @@ template <typename T> struct Solver final : mmw_solver {
     bool last_was_rng = false;
 
     ~Solver() override {
+        if (blk_thread.joinable()) blk_thread.join();  // it works on this handle's members
         if (host_only) return;
         (void)hipSetDevice(device);
         for (auto e : events) (void)hipEventDestroy(e);
@@ -137,7 +138,18 @@ template <typename T> struct Solver final : mmw_solver {
                 (void)hipFree(p);
             });
         struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{warm_thread};
-        std::string err = build_pattern(H, K_, Z_, Sp, Si, Sx, Qp, Qi, Qx, h);
+        {   // whether the matrix-core blocking is wanted depends on the block's padded width only
+            BlockLayout lay0;
+            std::string lerr;
+            blk_want_mf = sizeof(T) == 4 && !getenv("MMW_NO_MFMA") && make_layout(Z_ * rr, V16<T>::N, lay0, lerr) == MMW_OK &&
+                          (double)K_ * lay0.Dpad * 4.0 < 4.0e9;
+        }
+        const char* blk_env = getenv("MMW_BLOCKING");
+        const bool start_blk = !host_only && !(blk_env && blk_env[0] == '0');
+        std::string err = build_pattern(H, K_, Z_, Sp, Si, Sx, Qp, Qi, Qx, h, [&]() {
+            if (start_blk) blk_thread = std::thread([this]() { host_blockings(); });
+        });
+        if (!err.empty() && blk_thread.joinable()) blk_thread.join();
         const double t_1 = tnow();
         if (!err.empty()) return fail(MMW_ERR_ARG, "mmw_create: " + err);
         K = K_; Z = Z_; rank_radio = rr; eta = eta_; nit = nit_;
@@ -148,6 +160,7 @@ template <typename T> struct Solver final : mmw_solver {
             if (getenv("MMW_HOST_BLOCKING")) {  // developer aid: build the locality blocking on the host and print its statistics
                 const double t0 = tnow();
                 build_blocking(HB, K, H.l_indptr, H.l_indices, blocking_limits<T>());
+                build_sd_tables(HB, K, H.l_indptr, H.l_indices);
                 fprintf(stderr, "[mmw] host blocking %.1f ms: usable %d half-tile %d blocks %d rows/block %.1f union/block %.1f reuse %.2f entries %lld (nnz %lld, +%.1f%% padding) sd2_rounds %d\n",
                         (tnow() - t0) * 1e3, (int)HB.usable, (int)HB.fits_half_tile, HB.nb(), (double)K / std::max(1, HB.nb()),
                         (double)HB.un_cols.size() / std::max(1, HB.nb()), HB.reuse, (long long)HB.nent, (long long)H.nnzL(),
@@ -160,6 +173,7 @@ template <typename T> struct Solver final : mmw_solver {
             if (getenv("MMW_CHECK_BLOCKING")) {  // CPU tests: build the blocking and check its invariants
                 const BlockingLimits lim = blocking_limits<T>();
                 if (HB.order.empty()) build_blocking(HB, K, H.l_indptr, H.l_indices, lim);
+                build_sd_tables(HB, K, H.l_indptr, H.l_indices);
                 if (!HB.order.empty() && !HB.blk_rowptr.empty() && HB.blk_rowptr.back() == K) {
                     const std::string berr = verify_blocking(HB, K, H.l_indptr, H.l_indices, lim);
                     if (!berr.empty()) return fail(MMW_ERR_STATE, "blocking invariant violated: " + berr);
@@ -225,33 +239,32 @@ template <typename T> struct Solver final : mmw_solver {
         B.half_tile = HB.fits_half_tile && (double)K * eng.lay.Dpad * sizeof(T) < 4.0e9 && !getenv("MMW_FULL_TILE");  // 32-bit byte offsets
         return B;
     }
-    int setup_blocking() {
-        const char* env = getenv("MMW_BLOCKING");
-        if (env && env[0] == '0') blocking_mode = 0;
-        if (!blocking_mode) return MMW_OK;
-        {   // both blockings start from the same RCM order and fill disjoint parts of HB: two host threads
-            const bool want_mf = sizeof(T) == 4 && !getenv("MMW_NO_MFMA") && (double)K * eng.lay.Dpad * 4.0 < 4.0e9;
-            bool rows_ok = true;
-            for (int k = 0; k < K && rows_ok; ++k) rows_ok = H.l_indptr[k + 1] - H.l_indptr[k] <= BLK_UNION;
-            if (rows_ok) HB.rcm_cache = rcm_order(K, H.l_indptr, H.l_indices);
-            const int mrows = getenv("MMW_MF_ROWS") ? atoi(getenv("MMW_MF_ROWS")) : 64;
-            std::thread mf_thread;
-            if (want_mf && rows_ok) mf_thread = std::thread([&]() { build_mfma_blocking(HB, K, H.l_indptr, H.l_indices, std::min(64, std::max(1, mrows))); });
-            build_blocking(HB, K, H.l_indptr, H.l_indices, blocking_limits<T>());
-            if (mf_thread.joinable()) mf_thread.join();
-            if (want_mf && getenv("MMW_VERBOSE"))
-                fprintf(stderr, "[mmw] matrix-core blocking: ok %d blocks %d rows/block %.1f reuse %.2f row tiles %d k-steps %d\n", (int)HB.fits_mfma, HB.nbm(),
-                        (double)K / std::max(1, HB.nbm()), HB.m_reuse, HB.mfma_mt, HB.kbase.empty() ? 0 : HB.kbase.back());
-        }
-        if (getenv("MMW_VERBOSE"))
-            fprintf(stderr, "[mmw] blocking: usable %d half-tile %d blocks %d rows/block %.1f union/block %.1f entries %lld (nnz %lld, +%.1f%% padding) sd_max %d\n",
-                    (int)HB.usable, (int)HB.fits_half_tile, HB.nb(), (double)K / std::max(1, HB.nb()), (double)HB.un_cols.size() / std::max(1, HB.nb()),
-                    (long long)HB.nent, (long long)H.nnzL(), 100.0 * ((double)HB.nent / (double)H.nnzL() - 1.0), HB.sd_max);
-        if (!HB.usable) return MMW_OK;
-        MMW_TRY(b_rowptr.upload(HB.blk_rowptr, st)); MMW_TRY(b_order.upload(HB.order, st)); MMW_TRY(b_unptr.upload(HB.un_ptr, st));
-        MMW_TRY(b_uncols.upload(HB.un_cols, st)); MMW_TRY(b_bptr.upload(HB.bptr, st)); MMW_TRY(b_bpos.upload(HB.bpos, st));
-        MMW_TRY(b_bepos.upload(HB.bepos, st)); MMW_TRY(b_lidx.upload(HB.lidx, st)); MMW_TRY(b_selfli.upload(HB.self_li, st)); MMW_TRY(b_desc.upload(HB.desc, st)); MMW_TRY(b_unfixed.upload(HB.un_fixed, st));
-        MMW_TRY(lval_blk.alloc((size_t)HB.nent));
+    // The host side of both blockings: one RCM order, then the two block builders on two threads (they fill disjoint parts of HB).
+    // Reads only the pattern's structure, so init() starts it while build_pattern is still making the mirrors and edge lists.
+    std::thread blk_thread;
+    bool blk_want_mf = false;
+    void host_blockings() {
+        const int Kp = H.K;
+        bool rows_ok = true;
+        for (int k = 0; k < Kp && rows_ok; ++k) rows_ok = H.l_indptr[k + 1] - H.l_indptr[k] <= BLK_UNION;
+        if (rows_ok) HB.rcm_cache = rcm_order(Kp, H.l_indptr, H.l_indices);
+        const int mrows = getenv("MMW_MF_ROWS") ? atoi(getenv("MMW_MF_ROWS")) : 64;
+        std::thread mf_thread;
+        if (blk_want_mf && rows_ok) mf_thread = std::thread([&]() { build_mfma_blocking(HB, Kp, H.l_indptr, H.l_indices, std::min(64, std::max(1, mrows))); });
+        build_blocking(HB, Kp, H.l_indptr, H.l_indices, blocking_limits<T>());
+        if (mf_thread.joinable()) mf_thread.join();
+    }
+    // Entry tables of the LDS-staged SDDMM kernels: built and uploaded on first need (a handle whose SDDMM runs on the matrix
+    // cores never asks; blocking.h, build_sd_tables)
+    bool sd_up = false;
+    int ensure_sd() {
+        if (sd_up || !HB.usable) return MMW_OK;
+        sd_up = true;
+        build_sd_tables(HB, K, H.l_indptr, H.l_indices);
+        // the block records carry every block's first slot of the half-tile SDDMM: refreshed in place (the kernels' argument
+        // structs hold this buffer's address)
+        if (b_desc.n != HB.desc.size()) return fail(MMW_ERR_STATE, "internal: block records changed size");
+        MMW_HIP(hipMemcpyAsync(b_desc.p, HB.desc.data(), HB.desc.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
         if (HB.sd_max <= SD_ROUNDS * BLK_THREADS) {
             MMW_TRY(b_sdptr.upload(HB.sd_ptr, st)); MMW_TRY(b_sdla.upload(HB.sd_la, st)); MMW_TRY(b_sdlb.upload(HB.sd_lb, st));
             MMW_TRY(b_sdepos.upload(HB.sd_epos, st));
@@ -292,6 +305,30 @@ template <typename T> struct Solver final : mmw_solver {
                                         std::max(HB.un8_max * B2_ROW_BYTES, 65536)));
             sddmm_blk2 = true;
         }
+        MMW_HIP(hipStreamSynchronize(st));  // the uploads read host vectors
+        return MMW_OK;
+    }
+    int setup_blocking() {
+        const char* env = getenv("MMW_BLOCKING");
+        if (env && env[0] == '0') blocking_mode = 0;
+        if (!blocking_mode) return MMW_OK;
+        if (blk_thread.joinable()) blk_thread.join();  // started under the pattern build (init)
+        else host_blockings();
+        {
+            const bool want_mf = blk_want_mf;
+            if (want_mf && getenv("MMW_VERBOSE"))
+                fprintf(stderr, "[mmw] matrix-core blocking: ok %d blocks %d rows/block %.1f reuse %.2f row tiles %d k-steps %d\n", (int)HB.fits_mfma, HB.nbm(),
+                        (double)K / std::max(1, HB.nbm()), HB.m_reuse, HB.mfma_mt, HB.kbase.empty() ? 0 : HB.kbase.back());
+        }
+        if (getenv("MMW_VERBOSE"))
+            fprintf(stderr, "[mmw] blocking: usable %d half-tile %d blocks %d rows/block %.1f union/block %.1f entries %lld (nnz %lld, +%.1f%% padding) sd_max %d\n",
+                    (int)HB.usable, (int)HB.fits_half_tile, HB.nb(), (double)K / std::max(1, HB.nb()), (double)HB.un_cols.size() / std::max(1, HB.nb()),
+                    (long long)HB.nent, (long long)H.nnzL(), 100.0 * ((double)HB.nent / (double)H.nnzL() - 1.0), HB.sd_max);
+        if (!HB.usable) return MMW_OK;
+        MMW_TRY(b_rowptr.upload(HB.blk_rowptr, st)); MMW_TRY(b_order.upload(HB.order, st)); MMW_TRY(b_unptr.upload(HB.un_ptr, st));
+        MMW_TRY(b_uncols.upload(HB.un_cols, st)); MMW_TRY(b_bptr.upload(HB.bptr, st)); MMW_TRY(b_bpos.upload(HB.bpos, st));
+        MMW_TRY(b_bepos.upload(HB.bepos, st)); MMW_TRY(b_lidx.upload(HB.lidx, st)); MMW_TRY(b_selfli.upload(HB.self_li, st)); MMW_TRY(b_desc.upload(HB.desc, st)); MMW_TRY(b_unfixed.upload(HB.un_fixed, st));
+        MMW_TRY(lval_blk.alloc((size_t)HB.nent));
         if (sizeof(T) == 4 && HB.fits_mfma) {
             MMW_TRY(b_kbase.upload(HB.kbase, st));
             MMW_TRY(b_fpos.upload(HB.fpos, st));
@@ -319,6 +356,7 @@ template <typename T> struct Solver final : mmw_solver {
                 MMW_TRY(eng.partial_o2.alloc((size_t)HB.nbm() * eng.lay.Dpad));
             }
         }
+        if (!sddmm_mfma) MMW_TRY(ensure_sd());
         MMW_HIP(hipStreamSynchronize(st));
         extras.fac.set_blocking(blkdev(), b_bepos.p, HB.nent);
         if (eng.use_mfma) extras.fac.set_mfma(eng.mf, HB.mfma_mt, b_fpos.p, afrag_n, (int64_t)H.nnzL());
@@ -840,6 +878,7 @@ template <typename T> struct Solver final : mmw_solver {
                     sd_done = true;
                 }
             }
+            if (!sd_done && eng.use_blk) MMW_TRY(ensure_sd());
             if (sd_done) {
             } else if (sddmm_blk2 && eng.use_blk) {
                 unsigned long long* sd_stamps = nullptr;  // MMW_SD_STAMPS=1: phase stamps of the last iteration's SDDMM

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -69,7 +70,9 @@ static inline std::string update_slots(HostPattern& P, int32_t Z) {
 // returns "" on success, else an error message
 static inline std::string build_pattern(HostPattern& P, int32_t K, int32_t Z, const int32_t* Sp, const int32_t* Si,
                                         const double* Sx, const int32_t* Qp, const int32_t* Qi, const double* Qx,
-                                        const double* h_max) {
+                                        const double* h_max, const std::function<void()>& on_structure = {}) {
+    // on_structure: called once l_indptr / l_indices are final (the mirror and edge-list passes still to come): the caller may
+    // start work that only reads the pattern's structure
     if (K < 2) return "K must be >= 2";
     if (Z < 2) return "Z must be >= 2 (the constraints divide by Z-1)";
     if (Sp[0] != 0 || Qp[0] != 0) return "indptr[0] must be 0";
@@ -209,6 +212,7 @@ static inline std::string build_pattern(HostPattern& P, int32_t K, int32_t Z, co
     }
     const int64_t nnz = P.nnzL();
     if (nnz > (int64_t)INT32_MAX) return "pattern too large for int32 indexing";
+    if (on_structure) on_structure();
     // ---- mirrors, edge lists.  The pattern is symmetric and every row is sorted, so while the rows a are swept in ascending
     // order the entries (b, a) of any row b are met in that row's own order: one cursor per row replaces a binary search per entry.
     P.mirror.assign(nnz, -1);
