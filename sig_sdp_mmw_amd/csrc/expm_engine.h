@@ -300,6 +300,11 @@ template <typename T> struct ExpmEngine {
     // wrote them (planes_ready)
     unsigned short* planes_of(int idx) { return planes.p + (size_t)idx * 2 * bs; }
     bool planes_ready[MAX_ORDER + 2] = {false};
+    int reserve_planes() {  // at creation: the planes of the Krylov blocks the matrix-core products read
+        if (planes.n < (size_t)ublocks * 2 * bs) MMW_TRY(planes.alloc((size_t)ublocks * 2 * bs));
+        for (auto& r : planes_ready) r = false;
+        return MMW_OK;
+    }
     int ensure_planes() {
         if (planes.n < (size_t)ublocks * 2 * bs) {
             MMW_HIP(hipStreamSynchronize(st));

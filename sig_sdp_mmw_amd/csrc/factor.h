@@ -104,6 +104,19 @@ template <typename T> struct DenseWork {
     }
     // Jacobi of G (b x b) -> eigenvalues in `diag`, eigenvectors in Q (one launch per round, ping-pong buffers)
     DevBuf<double> bjH[2], bjQ[2], bjR;
+    int reserve_jacobi(int b) {
+        int M = (b + BJ_NB - 1) / BJ_NB;
+        M = std::max(2, M + (M & 1));
+        const size_t pp = (size_t)BJ_NB * M * BJ_NB * M;
+        for (int q = 0; q < 2; ++q) {
+            if (bjH[q].n < pp) MMW_TRY(bjH[q].alloc(pp));
+            if (bjQ[q].n < pp) MMW_TRY(bjQ[q].alloc(pp));
+        }
+        if (bjR.n < (size_t)(M / 2) * BJ_N2 * BJ_N2) MMW_TRY(bjR.alloc((size_t)(M / 2) * BJ_N2 * BJ_N2));
+        if (flag.n < 1) MMW_TRY(flag.alloc(1));
+        if (dfac.n < (size_t)CH_NB * CH_NB) MMW_TRY(dfac.alloc((size_t)CH_NB * CH_NB));
+        return MMW_OK;
+    }
     // block Jacobi (kernels_dense.h, k_bj_solve / k_bj_apply): two launches per block round, M - 1 block rounds per sweep
     int jacobi_blocked(int b, double rel_tol, int max_sweeps, int* sweeps_done) {
         int M = (b + BJ_NB - 1) / BJ_NB;
@@ -317,13 +330,36 @@ template <typename T> struct Factorizer {
         return MMW_OK;
     }
 
+    // block width and padded width run() uses for a given rank
+    static int block_width(int K, int rank) {
+        int b = std::min(K, rank + std::max(12, rank / 5));
+        if (K <= 384 || 4 * b >= 3 * K) b = K;
+        return b;
+    }
+    // the buffers run() sizes on first use, reserved ahead (handle creation)
+    int reserve(int rank, bool mf_possible) {
+        const int b = block_width(K, rank);
+        BlockLayout lay;
+        std::string err;
+        if (make_layout(b, V16<T>::N, lay, err) != MMW_OK) return MMW_OK;  // run() reports it
+        const size_t bs = (size_t)K * lay.Dpad;
+        const size_t want = (mf_possible && sizeof(T) == 4 && lay.Dpad % 32 == 0 && b < K) ? 2 * bs : bs;
+        if (V.n < want) { MMW_TRY(V.alloc(want)); MMW_TRY(W.alloc(want)); MMW_TRY(Y1.alloc(want)); MMW_TRY(Y2.alloc(want)); }
+        if (partial.n < (size_t)MAX_PART * lay.Dpad) MMW_TRY(partial.alloc((size_t)MAX_PART * lay.Dpad));
+        if (colsum.n < (size_t)lay.Dpad) MMW_TRY(colsum.alloc(lay.Dpad));
+        if (rho_part.n < (size_t)MAX_PART) MMW_TRY(rho_part.alloc(MAX_PART));
+        if (out64.n < (size_t)K * rank) MMW_TRY(out64.alloc((size_t)K * rank));
+        MMW_TRY(dw.ensure(b, 16));
+        MMW_TRY(dw.reserve_jacobi(b));
+        return MMW_OK;
+    }
+
     // factor of A = ascale * (values `val` on the pattern).  out: K*rank float64 (host)
     int run(const int* indptr, const int* col, const T* val, double ascale, int rank, uint64_t seed, double* out) {
         if (rank < 1 || rank >= K + 1) return fail(MMW_ERR_ARG, "mmw_factor: rank must be in [1, K]");
         const bool f32 = sizeof(T) == 4;
         const double tol = f32 ? 2e-5 : 1e-9;
-        int b = std::min(K, rank + std::max(12, rank / 5));
-        if (K <= 384 || 4 * b >= 3 * K) b = K;  // small or nearly full: one exact Rayleigh-Ritz on the whole space
+        const int b = block_width(K, rank);  // small or nearly full: one exact Rayleigh-Ritz on the whole space
         BlockLayout lay;
         std::string err;
         if (make_layout(b, V16<T>::N, lay, err) != MMW_OK) return fail(MMW_ERR_ARG, "mmw_factor: " + err);

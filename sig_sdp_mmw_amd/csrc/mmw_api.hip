@@ -220,6 +220,7 @@ template <typename T> struct Solver final : mmw_solver {
         eng.max_order = 12;
         eng.tol = sizeof(T) == 4 ? 1e-6 : 1e-9;
         MMW_TRY(Xh.alloc(eng.bs));
+        MMW_TRY(prealloc());
         const double t_2 = tnow();
         MMW_TRY(setup_blocking());
         const double t_3 = tnow();
@@ -238,6 +239,25 @@ template <typename T> struct Solver final : mmw_solver {
         B.bptr = b_bptr.p; B.lidx = b_lidx.p; B.self_li = b_selfli.p; B.desc = b_desc.p; B.un_fixed = b_unfixed.p;
         B.half_tile = HB.fits_half_tile && (double)K * eng.lay.Dpad * sizeof(T) < 4.0e9 && !getenv("MMW_FULL_TILE");  // 32-bit byte offsets
         return B;
+    }
+    // Buffers the loop, the factor and the rounding would otherwise allocate on first use (hipMalloc is a synchronous driver call
+    // of 0.1 - 3 ms, and the first probe of a search pays all of them inside its timed phases): reserved here, while the
+    // blocking thread is still at work and this thread would only wait for it.
+    int prealloc() {
+        const size_t nnz = (size_t)H.nnzL(), C = (size_t)H.C();
+        for (DevBuf<T>* b : {&sn_lval, &sn_xval, &sn_xavg}) MMW_TRY(b->alloc(nnz));
+        for (DevBuf<T>* b : {&sn_Y, &sn_yavg, &sn_eaccu, &yun}) MMW_TRY(b->alloc(C));
+        MMW_TRY(sn_plan.alloc(1));
+        if (blk_want_mf && (eng.lay.Dpad % 32) == 0) {
+            MMW_TRY(xh_planes.alloc(2 * eng.bs));
+            MMW_TRY(eng.reserve_planes());
+        }
+        const int rank = std::min(K - 1, (Z - 1) * rank_radio);  // what the host class asks mmw_factor for (mmw.py:206)
+        if (rank >= 1) {
+            MMW_TRY(extras.fac_reserve(st, K, rank, blk_want_mf));
+            if ((size_t)10 * K * Z * sizeof(double) <= ((size_t)2 << 30)) MMW_TRY(extras.round_reserve(K, Z, rank, 10));  // sdp_solver.rounding's 10 attempts
+        }
+        return MMW_OK;
     }
     // The host side of both blockings: one RCM order, then the two block builders on two threads (they fill disjoint parts of HB).
     // Reads only the pattern's structure, so init() starts it while build_pattern is still making the mirrors and edge lists.

@@ -150,6 +150,20 @@ template <typename T> struct Extras {
         return MMW_OK;
     }
 
+    // handle creation: the buffers the factor and one batched rounding call of (Z, D', nbatch) would size on first use
+    int fac_reserve(hipStream_t s, int K_, int rank, bool mf_possible) {
+        fac.st = s; fac.K = K_; fac.dw.st = s;
+        return fac.reserve(rank, mf_possible);
+    }
+    int round_reserve(int K_, int32_t Z, int32_t Dp, int32_t nb) {
+        const size_t nP = (size_t)nb * K_ * Z;
+        MMW_TRY(ensure(gX, (size_t)K_ * Dp)); MMW_TRY(ensure(randv, (size_t)nb * Z * Dp));
+        MMW_TRY(ensure(P, nP)); MMW_TRY(ensure(pref, nP)); MMW_TRY(ensure(gain, nP));
+        MMW_TRY(ensure(slot, (size_t)nb * K_)); MMW_TRY(ensure(nrm, K_)); MMW_TRY(ensure(order, K_)); MMW_TRY(ensure(rem, nb));
+        MMW_TRY(ensure(glag, (size_t)K_));
+        return MMW_OK;
+    }
+
     int round(int32_t Z, int32_t Dp, const double* gX_h, int32_t nb, const double* randv_h, int32_t* z_out, int32_t* rem_out) {
         if (Z < 1 || Dp < 1 || nb < 1) return fail(MMW_ERR_ARG, "mmw_round: Z, D' and nbatch must be positive");
         if (!gX_h || !randv_h || !z_out || !rem_out) return fail(MMW_ERR_ARG, "mmw_round: null pointer");
