@@ -248,6 +248,9 @@ template <typename T> struct Solver final : mmw_solver {
         for (DevBuf<T>* b : {&sn_lval, &sn_xval, &sn_xavg}) MMW_TRY(b->alloc(nnz));
         for (DevBuf<T>* b : {&sn_Y, &sn_yavg, &sn_eaccu, &yun}) MMW_TRY(b->alloc(C));
         MMW_TRY(sn_plan.alloc(1));
+        // Krylov basis: the first iterations of a run ask for 2 - 3 steps before the a-posteriori estimate settles on fewer; growing
+        // the basis there costs an allocation, a copy and two device synchronisations each time
+        if ((double)eng.bs * sizeof(T) * 4.0 < 8.0e9) MMW_TRY(eng.ensure_blocks(std::min(4, eng.max_order + 1)));
         if (blk_want_mf && (eng.lay.Dpad % 32) == 0) {
             MMW_TRY(xh_planes.alloc(2 * eng.bs));
             MMW_TRY(eng.reserve_planes());
