@@ -303,11 +303,22 @@ def main():
             except Exception:
                 pass
     kinfo = solver.spmm_kernel_info()
+    # the same kernel on the same matrix, 30 launches inside ONE pair of events: the bracket of the per-launch measurement above
+    # (event markers + the dispatch after a host synchronisation, ~5 us) amortised; this is the figure rocprofv3's mean agrees with
+    b2b_us = None
+    try:
+        os.environ["MMW_BENCH_LANCZOS"] = "1"
+        b2b_us = solver.bench_spmm({0: 0, 1: 1, 2: 1, 3: 2}[int(solver.read(_lib.F_SPMM_KIND)[0])], 30)  # generic / LDS-staged / matrix cores
+    except Exception:
+        b2b_us = None
+    finally:
+        os.environ.pop("MMW_BENCH_LANCZOS", None)
     roofline = {"bound": "hbm", "kernel": kinfo["name"] + " of the %s step" % args.expm, "limiter": kinfo["limiter"],
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_source": traffic_src if traffic is not None else None,
-                "bytes_per_launch": int(b_spmm), "avg_launch_us": round(spmm_avg_us, 2), "launches": int(spmm_n),
+                "bytes_per_launch": int(b_spmm), "avg_launch_us": round(spmm_avg_us, 2),
+                "avg_launch_us_back_to_back": None if b2b_us is None else round(b2b_us, 2), "launches": int(spmm_n),
                 "launches_per_step": round(spmm_n / max(args.steps, 1), 2)}
     phases = {k: round(v[0] / max(args.steps, 1), 2) for k, v in kt.items() if v[1]}
 
