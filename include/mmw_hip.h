@@ -106,7 +106,9 @@ int mmw_set_expm(mmw_solver* s, int method, int max_order, double tol);
 /* 1: record HIP events around every phase (fills MMW_F_PHASE_US); 0: none, iterations run back to back. */
 int mmw_set_timing(mmw_solver* s, int enabled);
 
-/* 1: bracket every kernel class with HIP events on the solver's stream (fills MMW_F_KERNEL_US); clears the sums */
+/* 1: bracket every kernel class with HIP events on the solver's stream (fills MMW_F_KERNEL_US), plans read back every iteration and
+ * every class in launches of its own, so launch counts are exact; 2: the same brackets around the launches of the shipped path as they
+ * are (chunks without readback, the sketch and the lagged plan riding in the LOSS launch); 0: off.  Clears the sums. */
 int mmw_set_profile(mmw_solver* s, int enabled);
 
 /* micro-benchmark of the dominant kernel on the handle's pattern and current L values: `reps` launches of the

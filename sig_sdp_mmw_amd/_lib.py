@@ -166,7 +166,8 @@ class Solver:
         self._timing = bool(on)
 
     def set_profile(self, on):
-        check(lib().mmw_set_profile(self._h, 1 if on else 0))
+        """False / 0: off; True / 1: synchronous mode with exact launch counts; 2: the shipped path as launched."""
+        check(lib().mmw_set_profile(self._h, int(on)))
 
     def kernel_times(self):
         """{class: (total device us, launches)} since set_profile(True)."""

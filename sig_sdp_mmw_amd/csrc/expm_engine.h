@@ -221,6 +221,7 @@ template <typename T> struct ExpmEngine {
     T* rownorm_d = nullptr;      // optional: the combination also emits ||y_row||^2 and its per-block sums (nblk slabs)
     double* rownorm_part = nullptr;
     unsigned short* out_planes = nullptr;  // optional (fp32): the combination also writes the result as bf16 hi / lo halves, interleaved per 32 columns (k_sddmm_mfma)
+    bool kt_exact = false;                 // the kernel timers are on in their synchronous mode (mmw_set_profile(s, 1))
     bool planes_only = false;              // ... and nothing else: no one reads this application's fp32 result
     bool start_colsq_ready = false;  // the producer of the start block already filled `partial` with its column sums of squares (npart_start slabs)
     int npart_start = 0;
@@ -458,7 +459,7 @@ template <typename T> struct ExpmEngine {
                     else if (j + 2 <= 8) MMW_LZS(8);
                     else MMW_LZS(MAX_ORDER + 2);
 #undef MMW_LZS
-                    if (kt && kt->on && apost() && j < m) {  // profiling counts exact launches: look at the estimate before going on
+                    if (kt && kt->on && kt_exact && apost() && j < m) {  // profiling mode 1 counts exact launches: look at the estimate before going on
                         MMW_TRY(kend());
                         MMW_HIP(hipMemcpyAsync(plan_h, plan_d.p, sizeof(ExpmPlan), hipMemcpyDeviceToHost, st));
                         MMW_HIP(hipStreamSynchronize(st));

@@ -49,6 +49,8 @@ template <typename T> struct Solver final : mmw_solver {
     int K = 0, Z = 0, D = 0, rank_radio = 2, nit = 0, iter = 0;
     double eta = 0.1;
     bool timing = false;
+    bool kt_shipped = false;  // set_profile(2)
+    bool kt_exact() const { return kt.on && !kt_shipped; }  // set_profile(1): synchronous plans, every kernel class in launches of its own
     // pattern on the device
     DevBuf<int> d_indptr, d_col, d_pid, d_mirror, d_diag, d_apos, d_lrow;
     DevBuf<T> d_sab, d_sba, d_h, d_ssum, d_invn, d_cH;
@@ -567,6 +569,8 @@ template <typename T> struct Solver final : mmw_solver {
         if (host_only) return fail(MMW_ERR_STATE, "host-only handle");
         MMW_TRY(sync());
         kt.on = enabled != 0;
+        kt_shipped = enabled == 2;  // 2: time the launches of the shipped path (chunks without readback, riding workgroups) as they are
+        eng.kt_exact = kt.on && !kt_shipped;
         kt.clear();
         return MMW_OK;
     }
@@ -718,7 +722,7 @@ template <typename T> struct Solver final : mmw_solver {
         if (n < 0) return fail(MMW_ERR_ARG, "n must be >= 0");
         MMW_TRY(settle());
         if (iter + n > nit) return fail(MMW_ERR_STATE, "mmw_iterate: more iterations than announced to mmw_create/mmw_reset");
-        const bool optimistic = randv == nullptr && n > 1 && !kt.on && !getenv("MMW_SYNC_PLAN");  // profiling counts exact launches
+        const bool optimistic = randv == nullptr && n > 1 && !kt_exact() && !getenv("MMW_SYNC_PLAN");  // profiling mode 1 counts exact launches
         if (!optimistic) return iterate_impl(n, randv, seed, false);
         // Chunks enqueued without plan readbacks.  Each chunk starts from a device snapshot; before the next one starts the
         // plan of the previous is looked at (one sync): a chunk that needed more steps than were launched is restored and
@@ -783,7 +787,7 @@ template <typename T> struct Solver final : mmw_solver {
         bool xavg_deferred = false;
         // drawing the next sketch in extra workgroups of the SDDMM launch paid off with 8-wave SDDMM workgroups (+3.7 %); with
         // 16-wave ones (two per CU, every wave slot taken) it costs 1.5 %, so it is opt-in
-        const bool fuse_sketch = !kt.on && !timing && getenv("MMW_FUSED_SKETCH") != nullptr;
+        const bool fuse_sketch = !kt_exact() && !timing && getenv("MMW_FUSED_SKETCH") != nullptr;
         sketch_done_for = -1;  // whatever an earlier batch left in the start block is not trusted
         for (int it = 0; it < n; ++it) {
             const int acc = (iter + 1 < nit) ? 1 : 0;  // the last X / Y are not averaged (mmw.py:77-78,203)
@@ -826,7 +830,7 @@ template <typename T> struct Solver final : mmw_solver {
             SketchArgs<T> skl{};
             const bool lz_m = eng.method == MMW_EXPM_LANCZOS;
             const bool sketch_have = !randv && sketch_done_for == (int64_t)iter && sketch_done_seed == seed;
-            if (!randv && !sketch_have && !kt.on && !timing && !getenv("MMW_NO_LOSS_SKETCH")) {
+            if (!randv && !sketch_have && !kt_exact() && !timing && !getenv("MMW_NO_LOSS_SKETCH")) {
                 skl.nblocks = sketch_slabs(); skl.K = K; skl.D = D; skl.seed = seed; skl.iter = (uint32_t)iter;
                 skl.R = eng.start_block();
                 skl.colsq_part = lz_m ? eng.partial_sq.p : nullptr;
@@ -847,7 +851,8 @@ template <typename T> struct Solver final : mmw_solver {
             MMW_TRY(kt.end());
             MMW_TRY(record(2));
             // ---- EXPM + X on the pattern
-            MMW_TRY(kt.begin(KT_SKETCH));
+            const bool sketch_rode = !randv && sketch_done_for == (int64_t)iter && sketch_done_seed == seed;  // nothing to launch, nothing to time
+            if (!sketch_rode) MMW_TRY(kt.begin(KT_SKETCH));
             if (randv) {
                 MMW_HIP(hipMemcpyAsync(stage64.p, randv + (size_t)it * K * D, (size_t)K * D * sizeof(double), hipMemcpyHostToDevice, st));
                 hipLaunchKernelGGL((k_import_block<T>), dim3(grid_elems(eng.bs)), dim3(BLOCK), 0, st, K, D, Dpad, stage64.p, eng.start_block());
@@ -862,7 +867,7 @@ template <typename T> struct Solver final : mmw_solver {
                 last_was_rng = true;
                 last_seed = seed;
             }
-            MMW_TRY(kt.end());
+            if (!sketch_rode) MMW_TRY(kt.end());
             MMW_HIP(hipGetLastError());
             // X on the pattern runs on the matrix cores too when the exponential did: the combination then also writes y's planes
             const bool sd_mf = sddmm_mfma && eng.use_blk && eng.method == MMW_EXPM_LANCZOS && (Dpad % 32) == 0;
@@ -950,7 +955,7 @@ template <typename T> struct Solver final : mmw_solver {
                 default: hipLaunchKernelGGL((k_sddmm<T, 4>), dim3(gr), dim3(BLOCK), 0, st, P, Dpad, eng.lay.LPR, eng.lay.G, Xh.p, drow.p, tr_part.p, gr, xval.p, xavg.p, acc); break;
             }
             // the running sum of X (mmw.py:77-78): one coalesced pass; none of the SDDMM kernels read-modify-writes xavg
-            if (acc && it + 1 < n && !kt.on) xavg_deferred = true;  // the next iteration's LOSS pass adds it
+            if (acc && it + 1 < n && !kt_exact()) xavg_deferred = true;  // the next iteration's LOSS pass adds it
             else if (acc) hipLaunchKernelGGL((k_accumulate<T>), dim3((unsigned)std::min<size_t>(((size_t)H.nnzL() + BLOCK - 1) / BLOCK, 4096)), dim3(BLOCK), 0, st, (size_t)H.nnzL(), xval.p, xavg.p);
             MMW_TRY(kt.end());
             MMW_HIP(hipGetLastError());

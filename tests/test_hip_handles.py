@@ -205,3 +205,29 @@ def test_fused_dual_pass_is_replayed_when_the_maximum_runs_away(monkeypatch):
     for f, x in zip(FIELDS, got):
         assert relerr(x, b.read(f)) < 1e-6, f  # as in test_replayed_chunk_equals_the_synchronous_run
     b.close()
+
+
+def test_profiling_the_shipped_path_does_not_change_it():
+    """mmw_set_profile(s, 2) brackets the launches of the shipped path as they are (chunks without readback, sketch and lagged plan
+    riding in the LOSS launch): same bits as the unprofiled run, no stand-alone sketch launches; mode 1 (synchronous, every class
+    in launches of its own) counts one sketch launch per iteration."""
+    state = journal_graph(16, 0.02, seed=4)
+    Z, nit = 24, 40
+    a = _lib.Solver(Z, state, nit, 0.04, dtype=_lib.F32)
+    a.iterate(nit, None, seed=9)
+    plain = [a.read(f) for f in FIELDS]
+    a.reset(nit)
+    a.set_profile(2)
+    a.iterate(nit, None, seed=9)
+    kt2 = a.kernel_times()
+    for f, x in zip(FIELDS, plain):
+        assert np.array_equal(x, a.read(f)), f
+    assert kt2["spmm"][1] >= nit and kt2["dual"][1] == nit and kt2["loss"][1] == nit
+    assert kt2["sketch"][1] <= 1 + nit // 4  # only a chunk's first iteration draws its sketch in a launch of its own
+    a.reset(nit)
+    a.set_profile(1)
+    a.iterate(nit, None, seed=9)
+    kt1 = a.kernel_times()
+    assert kt1["sketch"][1] == nit
+    a.set_profile(0)
+    a.close()
