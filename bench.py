@@ -135,13 +135,14 @@ def spawn_ranks(n, cmd, env=None, timeout=None):
     return rc, out0
 
 
-def coloring_block(state, dtype_name, nit, eta, warm, geometry=None):
+def coloring_block(state, dtype_name, nit, eta, warm, geometry=None, speculate=False):
     """Wall-clock of the whole binary search (binary_search_relaxation.run) to a feasible colouring, with the device-RNG /
     batched-rounding fast path of the drop-in class (the flow of sim_script/journal_version/sim_mmw_time.py:30-36)."""
     from sig_sdp_mmw_amd.binary_search import binary_search_relaxation
     from sig_sdp_mmw_amd.mmw import mmw
     bs = binary_search_relaxation()
     bs.verbose = False
+    bs.speculate = bool(speculate)
     alg = mmw(nit=nit, eta=eta, dtype=dtype_name, rng="device", seed=1, warm_start=warm)
     bs.feasibility_check_alg = alg
     np.random.seed(0)
@@ -164,10 +165,12 @@ def coloring_block(state, dtype_name, nit, eta, warm, geometry=None):
         env.close()
     return {"wall_s": round(wall, 4), "Z": int(Z), "rem": int(rem), "probes": int(per.shape[0]), "nit_per_probe": int(nit), "score": score,
             "warm_start": bool(warm), "mids": [int(x) for x in per[:, 5]], "rems": [int(x) for x in per[:, 7]],
-            "iterations": [int(x) for x in lg["mmw_iters"][:, 5]] if "mmw_iters" in lg else None,
-            "per_probe_ms": {"solve": [ms(x) for x in per[:, 8]], "rounding": [ms(x) for x in per[:, 9]],
-                             "state_process": [ms(x) for x in lg["mmw_state_process"][:, 5]],
-                             "factor": [ms(x) for x in lg["mmw_xavg"][:, 5]]}}
+            "iterations": [int(x) for x in lg["mmw_iters"][:, 5]] if "mmw_iters" in lg and not speculate else None,
+            "speculation": ({"probes_solved_ahead_and_dropped": int(bs.LOGGED_NP_DATA["bs_speculation"][0, 4])}
+                            if speculate and "bs_speculation" in bs.LOGGED_NP_DATA else None),
+            "per_probe_ms": dict({"solve": [ms(x) for x in per[:, 8]], "rounding": [ms(x) for x in per[:, 9]]},
+                                 **({} if speculate else {"state_process": [ms(x) for x in lg["mmw_state_process"][:, 5]],
+                                                          "factor": [ms(x) for x in lg["mmw_xavg"][:, 5]]}))}
 
 
 def main():
@@ -183,6 +186,7 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=-1, help="oracle iterations for cpu_baseline (-1: auto, 0: skip)")
     ap.add_argument("--no-coloring", action="store_true", help="skip the binary search to a converged colouring")
     ap.add_argument("--coloring-nit", type=int, default=150)
+    ap.add_argument("--coloring-speculate", action="store_true", help="two probes in flight on two handles (binary_search.speculate; opt-in)")
     ap.add_argument("--coloring-cold", action="store_true", help="every probe restarts from Y = 1/C, X = I like the reference (mmw.py:62-68)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --single-device rehearses N>1 on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="every rank uses GPU 0 (rehearsal only)")
@@ -350,7 +354,8 @@ def main():
     if rank == 0 and world == 1 and M == 1 and not args.no_coloring:
         for s in solvers[1:]:
             s.close()
-        out["coloring"] = coloring_block(state, dtype_name, args.coloring_nit, args.eta, warm=not args.coloring_cold, geometry=geometry0)
+        out["coloring"] = coloring_block(state, dtype_name, args.coloring_nit, args.eta, warm=not args.coloring_cold, geometry=geometry0,
+                                         speculate=args.coloring_speculate)
 
     # ---- CPU baseline: the oracle on this host, bounded sample of the same instance (rank 0, N = 1 only)
     if rank == 0 and world == 1 and args.cpu_iters != 0:

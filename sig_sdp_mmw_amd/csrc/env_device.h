@@ -286,11 +286,11 @@ struct EnvDevice {
         MMW_HIP(hipSetDevice(device));
         memcpy(Sp, h_sptr.data(), (size_t)(K + 1) * sizeof(int32_t));
         memcpy(Qp, h_qptr.data(), (size_t)(K + 1) * sizeof(int32_t));
-        MMW_HIP(hipMemcpyAsync(Si, s_idx.p, (size_t)nnzS * sizeof(int), hipMemcpyDeviceToHost, st));
-        MMW_HIP(hipMemcpyAsync(Sx, s_val.p, (size_t)nnzS * sizeof(double), hipMemcpyDeviceToHost, st));
-        MMW_HIP(hipMemcpyAsync(Qi, q_idx.p, (size_t)nnzQ * sizeof(int), hipMemcpyDeviceToHost, st));
-        MMW_HIP(hipMemcpyAsync(Qx, q_val.p, (size_t)nnzQ * sizeof(double), hipMemcpyDeviceToHost, st));
-        MMW_HIP(hipMemcpyAsync(h, h_max.p, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, st));
+        MMW_TRY(copy_d2h(Si, s_idx.p, (size_t)nnzS * sizeof(int), st));
+        MMW_TRY(copy_d2h(Sx, s_val.p, (size_t)nnzS * sizeof(double), st));
+        MMW_TRY(copy_d2h(Qi, q_idx.p, (size_t)nnzQ * sizeof(int), st));
+        MMW_TRY(copy_d2h(Qx, q_val.p, (size_t)nnzQ * sizeof(double), st));
+        MMW_TRY(copy_d2h(h, h_max.p, (size_t)K * sizeof(double), st));
         MMW_HIP(hipStreamSynchronize(st));
         return MMW_OK;
     }

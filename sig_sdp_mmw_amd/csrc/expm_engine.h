@@ -275,6 +275,14 @@ template <typename T> struct ExpmEngine {
     int ensure_blocks(int n) {
         if (n <= ublocks) return MMW_OK;
         if (n > MAX_ORDER + 1) n = MAX_ORDER + 1;
+        if (U.p && U.cap >= bs * (size_t)n) {  // room left from a wider run of this handle: no allocation, the start block stays where it is
+            if ((size_t)n > (size_t)std::max(ublocks, 1))
+                MMW_HIP(hipMemsetAsync(U.p + bs * (size_t)std::max(ublocks, 1), 0, bs * (size_t)(n - std::max(ublocks, 1)) * sizeof(T), st));
+            if (ublocks == 0) MMW_HIP(hipMemsetAsync(U.p, 0, bs * sizeof(T), st));
+            U.n = bs * (size_t)n;
+            ublocks = n;
+            return MMW_OK;
+        }
         DevBuf<T> bigger;
         MMW_TRY(bigger.alloc(bs * (size_t)n));
         MMW_HIP(hipMemsetAsync(bigger.p, 0, bs * (size_t)n * sizeof(T), st));
@@ -282,6 +290,7 @@ template <typename T> struct ExpmEngine {
         MMW_HIP(hipStreamSynchronize(st));
         std::swap(U.p, bigger.p);
         std::swap(U.n, bigger.n);
+        std::swap(U.cap, bigger.cap);
         ublocks = n;
         return MMW_OK;
     }

@@ -6,6 +6,7 @@
 //     Lanczos recurrence whose small tridiagonal is examined on the host (Sturm bisection).
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <numeric>
 
@@ -243,7 +244,8 @@ template <typename T> struct Factorizer {
     DenseWork<T> dw;
     DevBuf<T> V, W, Y1, Y2;      // K x ld blocks
     DevBuf<double> partial, colsum, rho_part, out64;
-    std::vector<double> last;    // [K*rank]
+    PinnedBuf last_host;         // [K*rank] float64: the last factor, page-locked (read back by MMW_F_FACTOR too)
+    size_t last_n = 0;
     int last_rank = 0;
 
     int outer_done = 0;
@@ -349,6 +351,7 @@ template <typename T> struct Factorizer {
         if (colsum.n < (size_t)lay.Dpad) MMW_TRY(colsum.alloc(lay.Dpad));
         if (rho_part.n < (size_t)MAX_PART) MMW_TRY(rho_part.alloc(MAX_PART));
         if (out64.n < (size_t)K * rank) MMW_TRY(out64.alloc((size_t)K * rank));
+        MMW_TRY(last_host.ensure((size_t)K * rank * sizeof(double)));
         MMW_TRY(dw.ensure(b, 16));
         MMW_TRY(dw.reserve_jacobi(b));
         return MMW_OK;
@@ -357,6 +360,8 @@ template <typename T> struct Factorizer {
     // factor of A = ascale * (values `val` on the pattern).  out: K*rank float64 (host)
     int run(const int* indptr, const int* col, const T* val, double ascale, int rank, uint64_t seed, double* out) {
         if (rank < 1 || rank >= K + 1) return fail(MMW_ERR_ARG, "mmw_factor: rank must be in [1, K]");
+        auto vnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double v_t0 = vnow();
         const bool f32 = sizeof(T) == 4;
         const double tol = f32 ? 2e-5 : 1e-9;
         const int b = block_width(K, rank);  // small or nearly full: one exact Rayleigh-Ritz on the whole space
@@ -376,28 +381,35 @@ template <typename T> struct Factorizer {
         if (colsum.n < (size_t)ld) MMW_TRY(colsum.alloc(ld));
         if (rho_part.n < (size_t)MAX_PART) MMW_TRY(rho_part.alloc(MAX_PART));
         MMW_TRY(dw.ensure(b, 16));
+        if (getenv("MMW_FACTOR_VERBOSE")) { (void)hipStreamSynchronize(st); fprintf(stderr, "[factor]   allocations done at %.1f ms\n", (vnow() - v_t0) * 1e3); }
         if (kt) MMW_TRY(kt->begin(KT_FACTOR));
         if (have_blk) {  // matrix values once into the blocked order (padding entries stay zero)
             if (val_blk.n < (size_t)nent) MMW_TRY(val_blk.alloc((size_t)nent));
             hipLaunchKernelGGL((k_gather_blocked<T>), dim3(grid_elems((size_t)nent)), dim3(BLOCK), 0, st, (size_t)nent, bepos, val, val_blk.p);
+            if (getenv("MMW_FACTOR_VERBOSE")) { (void)hipStreamSynchronize(st); fprintf(stderr, "[factor]   gather blocked at %.1f ms\n", (vnow() - v_t0) * 1e3); }
         }
         if constexpr (sizeof(T) == 4) {
             if (mf_use) {
                 if (afrag.n < mf_image) MMW_TRY(afrag.alloc(mf_image));
                 MMW_HIP(hipMemsetAsync(afrag.p, 0, mf_image * sizeof(unsigned), st));
+                if (getenv("MMW_FACTOR_VERBOSE")) { (void)hipStreamSynchronize(st); fprintf(stderr, "[factor]   memset image at %.1f ms\n", (vnow() - v_t0) * 1e3); }
                 hipLaunchKernelGGL((k_refrag<T>), dim3(grid_elems((size_t)mf_nnz)), dim3(BLOCK), 0, st, (size_t)mf_nnz, val, mf_fpos, afrag.p);
+                if (getenv("MMW_FACTOR_VERBOSE")) { (void)hipStreamSynchronize(st); fprintf(stderr, "[factor]   refrag at %.1f ms\n", (vnow() - v_t0) * 1e3); }
                 mf.afrag = afrag.p;
             }
         }
+        if (getenv("MMW_FACTOR_VERBOSE")) { (void)hipStreamSynchronize(st); fprintf(stderr, "[factor]   matrix copies done at %.1f ms\n", (vnow() - v_t0) * 1e3); }
         // spectral scale: ||A||_1 >= |lambda|_max
         hipLaunchKernelGGL((k_rowabs<T>), dim3(nblk), dim3(BLOCK), 0, st, K, indptr, col, val, ascale, (const double*)nullptr, 0, rho_part.p);
         std::vector<double> hp(nblk);
         MMW_HIP(hipMemcpyAsync(hp.data(), rho_part.p, nblk * sizeof(double), hipMemcpyDeviceToHost, st));
         MMW_HIP(hipStreamSynchronize(st));
         const double rho = *std::max_element(hp.begin(), hp.end());
+        if (getenv("MMW_FACTOR_VERBOSE")) { (void)hipStreamSynchronize(st); fprintf(stderr, "[factor]   norm bound done at %.1f ms\n", (vnow() - v_t0) * 1e3); }
         // random start block (rows of unit norm; any full-rank start works)
         hipLaunchKernelGGL((k_sketch_rng<T>), dim3(nblk), dim3(BLOCK), 0, st, K, b, ld, seed ^ 0x9E3779B97F4A7C15ull, 0u, V.p, (double*)nullptr);
         MMW_TRY(orthonormalise(b, ld, V, W, 1e-14));
+        if (getenv("MMW_FACTOR_VERBOSE")) { (void)hipStreamSynchronize(st); fprintf(stderr, "[factor]   start block orthonormal at %.1f ms\n", (vnow() - v_t0) * 1e3); }
         std::vector<double> theta(b), res(b), hres((size_t)64 * b);
         std::vector<int> perm(b);
         std::vector<double> ones(b, 1.0);
@@ -470,7 +482,7 @@ template <typename T> struct Factorizer {
             }
             const double scale_top = std::max(std::fabs(theta[0]), 1e-300);
             last_resid = worst / scale_top;
-            if (getenv("MMW_FACTOR_VERBOSE")) fprintf(stderr, "[factor]   outer %d degree %d resid %.2e\n", outer, degree, last_resid);
+            if (getenv("MMW_FACTOR_VERBOSE")) fprintf(stderr, "[factor]   outer %d degree %d resid %.2e at %.1f ms\n", outer, degree, last_resid, (vnow() - v_t0) * 1e3);
             if (!skip_rr && (b >= K || last_resid <= tol)) {
                 done = true;
                 break;
@@ -530,6 +542,7 @@ template <typename T> struct Factorizer {
         }
         outer_done = outer;
         if (kt) MMW_TRY(kt->end());
+        if (getenv("MMW_FACTOR_VERBOSE")) fprintf(stderr, "[factor]   iteration done at %.1f ms\n", (vnow() - v_t0) * 1e3);
         if (getenv("MMW_FACTOR_VERBOSE"))
             fprintf(stderr, "[factor] K=%d rank=%d b=%d outer=%d degree_last=%d resid=%.2e jacobi_sweeps=%d jacobi_calls=%d\n", K, rank, b, outer, degree,
                     last_resid, dw.sweeps_total, dw.calls_total);
@@ -547,13 +560,17 @@ template <typename T> struct Factorizer {
         MMW_HIP(hipMemcpyAsync(dw.diag.p, sc.data(), rank * sizeof(double), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL((k_export_factor<T>), dim3(grid_elems((size_t)K * rank)), dim3(BLOCK), 0, st, K, rank, ld, V.p, dw.perm.p, dw.diag.p, out64.p);
         MMW_HIP(hipGetLastError());
-        last.resize((size_t)K * rank);
-        MMW_HIP(hipMemcpyAsync(last.data(), out64.p, (size_t)K * rank * sizeof(double), hipMemcpyDeviceToHost, st));
+        last_n = 0;
+        MMW_TRY(last_host.ensure((size_t)K * rank * sizeof(double)));
+        MMW_HIP(hipMemcpyAsync(last_host.p, out64.p, (size_t)K * rank * sizeof(double), hipMemcpyDeviceToHost, st));
         MMW_HIP(hipStreamSynchronize(st));
+        last_n = (size_t)K * rank;
         last_rank = rank;
+        if (getenv("MMW_FACTOR_VERBOSE")) fprintf(stderr, "[factor]   export + copy-out done at %.1f ms\n", (vnow() - v_t0) * 1e3);
 
         // restore the unit column scales used by k_select_cols
-        if (out) memcpy(out, last.data(), last.size() * sizeof(double));
+        if (out) memcpy(out, last_host.p, last_n * sizeof(double));
+        if (getenv("MMW_FACTOR_VERBOSE")) fprintf(stderr, "[factor]   host copy done at %.1f ms\n", (vnow() - v_t0) * 1e3);
         return MMW_OK;
     }
 };

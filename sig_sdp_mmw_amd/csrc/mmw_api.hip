@@ -854,7 +854,7 @@ template <typename T> struct Solver final : mmw_solver {
             const bool sketch_rode = !randv && sketch_done_for == (int64_t)iter && sketch_done_seed == seed;  // nothing to launch, nothing to time
             if (!sketch_rode) MMW_TRY(kt.begin(KT_SKETCH));
             if (randv) {
-                MMW_HIP(hipMemcpyAsync(stage64.p, randv + (size_t)it * K * D, (size_t)K * D * sizeof(double), hipMemcpyHostToDevice, st));
+                MMW_TRY(copy_h2d(stage64.p, randv + (size_t)it * K * D, (size_t)K * D * sizeof(double), st));  // page-locked staging (runtime.h)
                 hipLaunchKernelGGL((k_import_block<T>), dim3(grid_elems(eng.bs)), dim3(BLOCK), 0, st, K, D, Dpad, stage64.p, eng.start_block());
                 eng.planes_ready[0] = false;  // an uploaded sketch is split by a pass of its own
                 last_was_rng = false;
@@ -983,8 +983,7 @@ template <typename T> struct Solver final : mmw_solver {
         if ((int64_t)n != have) return fail(MMW_ERR_ARG, "mmw_read_f64: wrong length " + std::to_string(have) + ", expected " + std::to_string(n));
         hipLaunchKernelGGL((k_to_f64<T>), dim3(grid_elems(n)), dim3(BLOCK), 0, st, n, src, out64.p);
         MMW_HIP(hipGetLastError());
-        MMW_HIP(hipMemcpyAsync(out, out64.p, n * sizeof(double), hipMemcpyDeviceToHost, st));
-        MMW_HIP(hipStreamSynchronize(st));
+        MMW_TRY(copy_d2h(out, out64.p, (size_t)n * sizeof(double), st));
         return MMW_OK;
     }
     int export_host(const std::vector<double>& v, double* out, int64_t have) {
@@ -997,8 +996,7 @@ template <typename T> struct Solver final : mmw_solver {
         if ((int64_t)n != have) return fail(MMW_ERR_ARG, "mmw_read_f64: wrong length for a K x D block");
         hipLaunchKernelGGL((k_export_block<T>), dim3(grid_elems(n)), dim3(BLOCK), 0, st, K, D, eng.lay.Dpad, src, out64.p);
         MMW_HIP(hipGetLastError());
-        MMW_HIP(hipMemcpyAsync(out, out64.p, n * sizeof(double), hipMemcpyDeviceToHost, st));
-        MMW_HIP(hipStreamSynchronize(st));
+        MMW_TRY(copy_d2h(out, out64.p, (size_t)n * sizeof(double), st));
         return MMW_OK;
     }
     int read_f64(int which, double* out, int64_t n) override {
@@ -1123,7 +1121,7 @@ int expm_apply_impl(int device, int method, int max_order, double tol, int32_t K
     MMW_TRY(d_out.alloc(eng.bs));
     MMW_TRY(d_b64.alloc((size_t)K * D));
     MMW_TRY(d_o64.alloc((size_t)K * D));
-    MMW_HIP(hipMemcpyAsync(d_b64.p, B, (size_t)K * D * sizeof(double), hipMemcpyHostToDevice, st));
+    MMW_TRY(copy_h2d(d_b64.p, B, (size_t)K * D * sizeof(double), st));
     hipEvent_t e0, e1;
     MMW_HIP(hipEventCreate(&e0));
     MMW_HIP(hipEventCreate(&e1));
@@ -1144,8 +1142,7 @@ int expm_apply_impl(int device, int method, int max_order, double tol, int32_t K
     (void)hipEventDestroy(e1);
     hipLaunchKernelGGL((k_export_block<T>), dim3(grid_elems((size_t)K * D)), dim3(BLOCK), 0, st, K, D, eng.lay.Dpad, d_out.p, d_o64.p);
     MMW_HIP(hipGetLastError());
-    MMW_HIP(hipMemcpyAsync(out, d_o64.p, (size_t)K * D * sizeof(double), hipMemcpyDeviceToHost, st));
-    MMW_HIP(hipStreamSynchronize(st));
+    MMW_TRY(copy_d2h(out, d_o64.p, (size_t)K * D * sizeof(double), st));
     if (info) {
         info[0] = eng.last.rho; info[1] = eng.last.m_eff > 0 ? eng.last.m_eff : eng.last.m; info[2] = eng.last.nsub; info[3] = eng.last.mu;
     }
@@ -1259,12 +1256,11 @@ int mmw_sym_eig(int device, int32_t b, const double* G, double rel_tol, int32_t 
     mmw::DenseWork<double> dw;
     dw.st = stream.s;
     MMW_TRY(dw.ensure(b, 1));
-    MMW_HIP(hipMemcpyAsync(dw.G.p, G, (size_t)b * b * sizeof(double), hipMemcpyHostToDevice, stream.s));
+    MMW_TRY(copy_h2d(dw.G.p, G, (size_t)b * b * sizeof(double), stream.s));
     int sw = 0;
     MMW_TRY(dw.jacobi(b, rel_tol, max_sweeps, &sw));
-    MMW_HIP(hipMemcpyAsync(theta, dw.diag.p, (size_t)b * sizeof(double), hipMemcpyDeviceToHost, stream.s));
-    MMW_HIP(hipMemcpyAsync(Q, dw.Q.p, (size_t)b * b * sizeof(double), hipMemcpyDeviceToHost, stream.s));
-    MMW_HIP(hipStreamSynchronize(stream.s));
+    MMW_TRY(copy_d2h(theta, dw.diag.p, (size_t)b * sizeof(double), stream.s));
+    MMW_TRY(copy_d2h(Q, dw.Q.p, (size_t)b * b * sizeof(double), stream.s));
     if (sweeps) *sweeps = sw;
     return MMW_OK;
 }

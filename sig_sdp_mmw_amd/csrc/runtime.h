@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -37,9 +40,83 @@ inline int fail(int code, const std::string& msg) {
         if (rc__ != MMW_OK) return rc__; \
     } while (0)
 
+// Page-locked host staging for the large transfers of a handle (the factor handed back, the rounding's inputs).  An asynchronous
+// copy to or from pageable memory makes the runtime pin the caller's pages and unpin them later, at a moment of its own choosing:
+// measured as 20 - 40 ms stalls in front of an unrelated launch of the next probe.  Copies go through this buffer instead.
+struct PinnedBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    int ensure(size_t bytes) {
+        if (p && bytes <= cap) return MMW_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        if (bytes == 0) bytes = 1;
+        MMW_HIP(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+        cap = bytes;
+        return MMW_OK;
+    }
+};
+
+// A small pool of such buffers for the one-off transfers (uploads at creation, API reads): leased for the duration of one copy.
+// The pool and its buffers live until the process ends (no destructor races with the HIP runtime's own teardown).
+struct StagePool {
+    std::mutex m;
+    std::vector<PinnedBuf*> idle;
+    PinnedBuf* get() {
+        std::lock_guard<std::mutex> g(m);
+        if (!idle.empty()) { PinnedBuf* b = idle.back(); idle.pop_back(); return b; }
+        return new PinnedBuf;
+    }
+    void put(PinnedBuf* b) { std::lock_guard<std::mutex> g(m); idle.push_back(b); }
+};
+inline StagePool& stage_pool() { static StagePool* pool = new StagePool; return *pool; }
+struct StageLease {
+    PinnedBuf* b;
+    StageLease() : b(stage_pool().get()) {}
+    ~StageLease() { stage_pool().put(b); }
+    StageLease(const StageLease&) = delete;
+    StageLease& operator=(const StageLease&) = delete;
+};
+constexpr size_t STAGE_MIN_BYTES = 64 << 10;  // smaller copies go straight: the runtime bounces them through its own pinned chunks
+// host -> device and back, synchronous on `st`; large ones through a leased page-locked buffer
+inline int copy_h2d(void* dst_dev, const void* src_host, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return MMW_OK;
+    if (bytes < STAGE_MIN_BYTES) {
+        MMW_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, st));
+        MMW_HIP(hipStreamSynchronize(st));
+        return MMW_OK;
+    }
+    StageLease L;
+    MMW_TRY(L.b->ensure(bytes));
+    memcpy(L.b->p, src_host, bytes);
+    MMW_HIP(hipMemcpyAsync(dst_dev, L.b->p, bytes, hipMemcpyHostToDevice, st));
+    MMW_HIP(hipStreamSynchronize(st));
+    return MMW_OK;
+}
+inline int copy_d2h(void* dst_host, const void* src_dev, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return MMW_OK;
+    if (bytes < STAGE_MIN_BYTES) {
+        MMW_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, st));
+        MMW_HIP(hipStreamSynchronize(st));
+        return MMW_OK;
+    }
+    StageLease L;
+    MMW_TRY(L.b->ensure(bytes));
+    MMW_HIP(hipMemcpyAsync(L.b->p, src_dev, bytes, hipMemcpyDeviceToHost, st));
+    MMW_HIP(hipStreamSynchronize(st));
+    memcpy(dst_host, L.b->p, bytes);
+    return MMW_OK;
+}
+
 template <typename T> struct DevBuf {
     T* p = nullptr;
-    size_t n = 0;
+    size_t n = 0;    // elements in use
+    size_t cap = 0;  // elements allocated
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
@@ -48,32 +125,33 @@ template <typename T> struct DevBuf {
         if (p) (void)hipFree(p);
         p = nullptr;
         n = 0;
+        cap = 0;
     }
+    // Contents are undefined afterwards.  An allocation that is large enough is kept: hipFree waits for the whole device (every
+    // stream of every handle), so a handle that shrinks its blocks for the next slot count must not free them.
     int alloc(size_t count) {
+        static const bool exact = getenv("MMW_DEVBUF_EXACT") != nullptr;
+        if (p && count <= cap && !exact) {
+            n = count;
+            return MMW_OK;
+        }
         release();
         n = count;
         if (count == 0) count = 1;
         MMW_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+        cap = count;
         return MMW_OK;
     }
     int upload(const std::vector<T>& h, hipStream_t st) {
         MMW_TRY(alloc(h.size()));
-        if (!h.empty()) {
-            MMW_HIP(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
-            MMW_HIP(hipStreamSynchronize(st));  // the source may be a short-lived host vector
-        }
-        return MMW_OK;
+        return copy_h2d(p, h.data(), h.size() * sizeof(T), st);  // synchronous: the source may be a short-lived host vector
     }
     // upload a double host vector converted to T
     template <typename S> int upload_cast(const std::vector<S>& h, hipStream_t st) {
         std::vector<T> tmp(h.size());
         for (size_t i = 0; i < h.size(); ++i) tmp[i] = (T)h[i];
         MMW_TRY(alloc(tmp.size()));
-        if (!tmp.empty()) {
-            MMW_HIP(hipMemcpyAsync(p, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice, st));
-            MMW_HIP(hipStreamSynchronize(st));  // tmp dies at scope exit
-        }
-        return MMW_OK;
+        return copy_h2d(p, tmp.data(), tmp.size() * sizeof(T), st);
     }
 };
 

@@ -145,8 +145,8 @@ template <typename T> struct Extras {
         return fac.run(indptr, col, xavg, 1.0 / (double)nit, rank, seed, out);
     }
     int read_factor(double* out, int64_t n) {
-        if ((int64_t)fac.last.size() != n || n == 0) return fail(MMW_ERR_STATE, "mmw_read_f64(FACTOR): no factor of that size has been computed");
-        memcpy(out, fac.last.data(), fac.last.size() * sizeof(double));
+        if ((int64_t)fac.last_n != n || n == 0) return fail(MMW_ERR_STATE, "mmw_read_f64(FACTOR): no factor of that size has been computed");
+        memcpy(out, fac.last_host.p, fac.last_n * sizeof(double));
         return MMW_OK;
     }
 
@@ -155,7 +155,9 @@ template <typename T> struct Extras {
         fac.st = s; fac.K = K_; fac.dw.st = s;
         return fac.reserve(rank, mf_possible);
     }
+    PinnedBuf stage;  // host side of mmw_round's transfers
     int round_reserve(int K_, int32_t Z, int32_t Dp, int32_t nb) {
+        MMW_TRY(stage.ensure((size_t)K_ * Dp * sizeof(double) + (size_t)nb * Z * Dp * sizeof(double) + (size_t)nb * K_ * sizeof(int) + 8 + (size_t)nb * sizeof(int)));
         const size_t nP = (size_t)nb * K_ * Z;
         MMW_TRY(ensure(gX, (size_t)K_ * Dp)); MMW_TRY(ensure(randv, (size_t)nb * Z * Dp));
         MMW_TRY(ensure(P, nP)); MMW_TRY(ensure(pref, nP)); MMW_TRY(ensure(gain, nP));
@@ -178,8 +180,15 @@ template <typename T> struct Extras {
         MMW_TRY(ensure(nrm, K));
         MMW_TRY(ensure(order, K));
         MMW_TRY(ensure(rem, nb));
-        MMW_HIP(hipMemcpyAsync(gX.p, gX_h, (size_t)K * Dp * sizeof(double), hipMemcpyHostToDevice, st));
-        MMW_HIP(hipMemcpyAsync(randv.p, randv_h, (size_t)nb * Z * Dp * sizeof(double), hipMemcpyHostToDevice, st));
+        // inputs and outputs cross through the handle's page-locked staging buffer (runtime.h, PinnedBuf)
+        const size_t b_gx = (size_t)K * Dp * sizeof(double), b_rv = (size_t)nb * Z * Dp * sizeof(double);
+        const size_t b_z = (((size_t)nb * K * sizeof(int)) + 7) & ~(size_t)7, b_rem = (size_t)nb * sizeof(int);
+        MMW_TRY(stage.ensure(b_gx + b_rv + b_z + b_rem));
+        char* sp = static_cast<char*>(stage.p);
+        memcpy(sp, gX_h, b_gx);
+        memcpy(sp + b_gx, randv_h, b_rv);
+        MMW_HIP(hipMemcpyAsync(gX.p, sp, b_gx, hipMemcpyHostToDevice, st));
+        MMW_HIP(hipMemcpyAsync(randv.p, sp + b_gx, b_rv, hipMemcpyHostToDevice, st));
         MMW_HIP(hipMemsetAsync(gain.p, 0, nP * sizeof(double), st));
         MMW_HIP(hipMemsetAsync(slot.p, 0xFF, (size_t)nb * K * sizeof(int), st));
         if (kt) MMW_TRY(kt->begin(KT_PROJECT));
@@ -239,9 +248,11 @@ template <typename T> struct Extras {
         }
         if (kt) MMW_TRY(kt->end());
         MMW_HIP(hipGetLastError());
-        MMW_HIP(hipMemcpyAsync(z_out, slot.p, (size_t)nb * K * sizeof(int), hipMemcpyDeviceToHost, st));
-        MMW_HIP(hipMemcpyAsync(rem_out, rem.p, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, st));
+        MMW_HIP(hipMemcpyAsync(sp + b_gx + b_rv, slot.p, (size_t)nb * K * sizeof(int), hipMemcpyDeviceToHost, st));
+        MMW_HIP(hipMemcpyAsync(sp + b_gx + b_rv + b_z, rem.p, b_rem, hipMemcpyDeviceToHost, st));
         MMW_HIP(hipStreamSynchronize(st));
+        memcpy(z_out, sp + b_gx + b_rv, (size_t)nb * K * sizeof(int));
+        memcpy(rem_out, sp + b_gx + b_rv + b_z, b_rem);
         return MMW_OK;
     }
 };

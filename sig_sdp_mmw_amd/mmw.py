@@ -63,6 +63,19 @@ class mmw(STATS_OBJECT, sdp_solver):
         self.warm_start = bool(warm_start)
         self.warm_fraction = float(warm_fraction)
 
+    def sibling(self):
+        """A second solver with the same settings and its own device handle, stream and sketch seeds (binary_search's opt-in
+        speculative mode keeps one probe in flight on each)."""
+        other = mmw(nit=self.nit, rank_radio=self.rank_radio, alpha=self.alpha, eta=self.eta, log_gap=self.LOG_GAP, dtype=self.dtype, rng=self.rng,
+                    expm=self.expm, expm_tol=self.expm_tol, expm_max_order=self.expm_max_order, device=self._device_index, seed=self.seed + 7919,
+                    warm_start=self.warm_start, warm_fraction=self.warm_fraction)
+        other.round_batch = self.round_batch
+        return other
+
+    def prepare(self, Z, state):
+        """State processing only (the device handle for `state`), so that a later run_with_state finds it there."""
+        self._device_solver(Z, state, nit=int(self.nit), eta=self.eta, need_loop=True, warm=False)
+
     def run_with_state(self, bs_iteration, Z, state):
         tic = self._get_tic()
         ret = self._run(Z, state)

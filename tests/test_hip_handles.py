@@ -231,3 +231,27 @@ def test_profiling_the_shipped_path_does_not_change_it():
     assert kt1["sketch"][1] == nit
     a.set_profile(0)
     a.close()
+
+
+def test_speculative_search_reaches_a_feasible_colouring_like_the_sequential_one():
+    """binary_search.speculate (opt-in): while `mid` is solved, the slot count that follows if it is feasible is solved on a second
+    handle in a second host thread; roundings run in the search's order.  Same update rules, so the search ends on a feasible
+    colouring within one slot of the sequential search's, after no more deciding probes than it."""
+    from sig_sdp_mmw_amd.binary_search import binary_search_relaxation
+    from sig_sdp_mmw_amd.mmw import mmw
+    state = journal_graph(16, 0.02, seed=3)
+    res = {}
+    for spec in (False, True):
+        bs = binary_search_relaxation()
+        bs.verbose = False
+        bs.speculate = spec
+        alg = mmw(nit=60, eta=0.04, dtype="f32", rng="device", seed=2, warm_start=True)
+        bs.feasibility_check_alg = alg
+        np.random.seed(0)
+        z_vec, Z, rem = bs.run(state)
+        alg.close()
+        assert rem == 0 and z_vec.min() >= 0 and z_vec.max() < Z
+        res[spec] = (Z, bs.LOGGED_NP_DATA["bs_search_per_it"].shape[0], bs.LOGGED_NP_DATA.get("bs_speculation"))
+    assert abs(res[True][0] - res[False][0]) <= 1
+    assert res[True][1] <= res[False][1] + 1
+    assert res[True][2] is not None and res[False][2] is None
