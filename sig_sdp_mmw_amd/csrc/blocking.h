@@ -9,6 +9,8 @@
 // Only the traversal order is permuted: the dense blocks, the value arrays and every index that crosses
 // the C-ABI stay in the caller's original user order.
 #pragma once
+#include <functional>
+#include <thread>
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
@@ -283,52 +285,84 @@ inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& i
     B.self_li.assign(K, 0);
     B.un8_max = 0;
     B.sd_ready = false;
-    B.lidx.clear();
-    B.bepos.clear();
-    B.lidx.reserve(nnz + (int64_t)K * 2 * BLK_CHUNK);
-    B.bepos.reserve(nnz + (int64_t)K * 2 * BLK_CHUNK);
     B.bpos.resize(nnz);
-    std::vector<int32_t> local(K, -1);
-    int64_t w = 0;
-    std::vector<std::pair<uint16_t, int32_t>> rowbuf, oddbuf;
-    for (int b = 0; b < B.nb(); ++b) {
-        if (b > 0)
-            for (int u = B.un_ptr[b - 1]; u < B.un_ptr[b]; ++u) local[B.un_cols[u]] = -1;
-        for (int u = B.un_ptr[b]; u < B.un_ptr[b + 1]; ++u) local[B.un_cols[u]] = u - B.un_ptr[b];
-        for (int q = B.blk_rowptr[b]; q < B.blk_rowptr[b + 1]; ++q) {
-            const int r = B.order[q];
-            B.self_li[q] = local[r] >= 0 ? (uint16_t)local[r] : (uint16_t)0;
-            // Entries in chunks of 16, eight staged rows of even local index and eight of odd: the half-tile kernel
-            // reads 128-byte staged rows with 8-lane groups, and the lane groups that share an LDS service group
-            // (0|3, 1|2, 4|7, 5|6) then always land on different bank halves.  Chunk positions with bit 2 clear
-            // hold even rows, the others odd rows; holes are (row 0 or 1, value 0) entries.
-            rowbuf.clear();
-            oddbuf.clear();
-            for (int e = indptr[r]; e < indptr[r + 1]; ++e) {
-                const uint16_t li = (uint16_t)local[indices[e]];
-                ((li & 1) ? oddbuf : rowbuf).emplace_back(li, e);
-            }
-            std::sort(rowbuf.begin(), rowbuf.end());
-            std::sort(oddbuf.begin(), oddbuf.end());
-            const int nch = std::max(1, (int)std::max((rowbuf.size() + 7) / 8, (oddbuf.size() + 7) / 8));
-            for (int c = 0; c < nch; ++c)
-                for (int p = 0; p < BLK_CHUNK; ++p) {
-                    const bool odd = (p & 4) != 0;
-                    const size_t i = (size_t)c * 8 + (p & 3) + ((p & 8) ? 4 : 0);
-                    const auto& src = odd ? oddbuf : rowbuf;
-                    if (i < src.size()) {
-                        B.lidx.push_back(src[i].first);
-                        B.bepos.push_back(src[i].second);
-                        B.bpos[src[i].second] = (int32_t)w;
-                    } else {
-                        B.lidx.push_back(odd ? 1 : 0);
-                        B.bepos.push_back(-1);
-                    }
-                    ++w;
-                }
-            B.bptr[q + 1] = (int32_t)w;
-        }
+    // Entries in chunks of 16, eight staged rows of even local index and eight of odd: the half-tile kernel
+    // reads 128-byte staged rows with 8-lane groups, and the lane groups that share an LDS service group
+    // (0|3, 1|2, 4|7, 5|6) then always land on different bank halves.  Chunk positions with bit 2 clear
+    // hold even rows, the others odd rows; holes are (row 0 or 1, value 0) entries.
+    // The blocks are independent here: a few host threads take contiguous runs of blocks, first to count every row's chunks
+    // (positions follow from a prefix sum), then to fill.
+    const int nbk = B.nb();
+    const int nthreads = std::max(1, std::min({4, nbk, (int)std::thread::hardware_concurrency()}));
+    std::vector<int> cut(nthreads + 1, nbk);
+    cut[0] = 0;
+    for (int t = 1; t < nthreads; ++t) {  // equal shares of the rows
+        const int target = (int)((int64_t)K * t / nthreads);
+        int bb = cut[t - 1];
+        while (bb < nbk && B.blk_rowptr[bb] < target) ++bb;
+        cut[t] = bb;
     }
+    auto run = [&](const std::function<void(int, int)>& body) {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nthreads; ++t) th.emplace_back(body, cut[t], cut[t + 1]);
+        body(cut[0], cut[1]);
+        for (auto& x : th) x.join();
+    };
+    std::vector<int32_t> nch_row(K, 1);
+    run([&](int b0, int b1) {
+        std::vector<int32_t> local(K, -1);
+        for (int b = b0; b < b1; ++b) {
+            for (int u = B.un_ptr[b]; u < B.un_ptr[b + 1]; ++u) local[B.un_cols[u]] = u - B.un_ptr[b];
+            for (int q = B.blk_rowptr[b]; q < B.blk_rowptr[b + 1]; ++q) {
+                const int r = B.order[q];
+                B.self_li[q] = local[r] >= 0 ? (uint16_t)local[r] : (uint16_t)0;
+                int ne = 0, no = 0;
+                for (int e = indptr[r]; e < indptr[r + 1]; ++e) ((local[indices[e]] & 1) ? no : ne)++;
+                nch_row[q] = std::max(1, std::max((ne + 7) / 8, (no + 7) / 8));
+            }
+            for (int u = B.un_ptr[b]; u < B.un_ptr[b + 1]; ++u) local[B.un_cols[u]] = -1;
+        }
+    });
+    int64_t w = 0;
+    for (int q = 0; q < K; ++q) {
+        w += (int64_t)nch_row[q] * BLK_CHUNK;
+        B.bptr[q + 1] = (int32_t)w;
+    }
+    B.lidx.assign((size_t)w, 0);
+    B.bepos.assign((size_t)w, -1);
+    run([&](int b0, int b1) {
+        std::vector<int32_t> local(K, -1);
+        std::vector<std::pair<uint16_t, int32_t>> rowbuf, oddbuf;
+        for (int b = b0; b < b1; ++b) {
+            for (int u = B.un_ptr[b]; u < B.un_ptr[b + 1]; ++u) local[B.un_cols[u]] = u - B.un_ptr[b];
+            for (int q = B.blk_rowptr[b]; q < B.blk_rowptr[b + 1]; ++q) {
+                const int r = B.order[q];
+                rowbuf.clear();
+                oddbuf.clear();
+                for (int e = indptr[r]; e < indptr[r + 1]; ++e) {
+                    const uint16_t li = (uint16_t)local[indices[e]];
+                    ((li & 1) ? oddbuf : rowbuf).emplace_back(li, e);
+                }
+                std::sort(rowbuf.begin(), rowbuf.end());
+                std::sort(oddbuf.begin(), oddbuf.end());
+                int64_t at = B.bptr[q];
+                for (int c = 0; c < nch_row[q]; ++c)
+                    for (int p = 0; p < BLK_CHUNK; ++p, ++at) {
+                        const bool odd = (p & 4) != 0;
+                        const size_t i = (size_t)c * 8 + (p & 3) + ((p & 8) ? 4 : 0);
+                        const auto& src = odd ? oddbuf : rowbuf;
+                        if (i < src.size()) {
+                            B.lidx[at] = src[i].first;
+                            B.bepos[at] = src[i].second;
+                            B.bpos[src[i].second] = (int32_t)at;
+                        } else {
+                            B.lidx[at] = odd ? 1 : 0;
+                        }
+                    }
+            }
+            for (int u = B.un_ptr[b]; u < B.un_ptr[b + 1]; ++u) local[B.un_cols[u]] = -1;
+        }
+    });
     B.nent = w;
     B.desc.assign((size_t)B.nb() * 8, 0);
     B.un_fixed.assign((size_t)B.nb() * BLK_UNION, 0);
@@ -501,20 +535,23 @@ inline void build_mfma_blocking(HostBlocking& B, int K, const std::vector<int32_
     if ((int64_t)B.kbase[nbm] * B.mfma_mt * 512 >= (int64_t)INT32_MAX || B.m_reuse < 2.0) return;
     const int MT = B.mfma_mt;
     B.fpos.assign(nnz, -1);
-    std::vector<int32_t> loc2(K, -1);
-    for (int b = 0; b < nbm; ++b) {
-        for (int u = un_ptr[b]; u < un_ptr[b + 1]; ++u) loc2[un_cols[u]] = u - un_ptr[b];
-        for (int q = B.m_rowptr[b]; q < B.m_rowptr[b + 1]; ++q) {
-            const int r = B.m_order[q], rl = q - B.m_rowptr[b];
-            for (int e = indptr[r]; e < indptr[r + 1]; ++e) {
-                const int li = loc2[indices[e]];
-                const int ks = li >> 4, j = li & 7, lane = (rl & 31) + 32 * ((li >> 3) & 1), mt = rl >> 5;
-                B.fpos[e] = ((((B.kbase[b] + ks) * MT + mt) * 2 + (j >> 2)) * 64 + lane) * 4 + (j & 3);
-            }
-        }
-        for (int u = un_ptr[b]; u < un_ptr[b + 1]; ++u) loc2[un_cols[u]] = -1;
+    // the blocks are independent from here on: contiguous runs of them on a few host threads
+    const int nthreads = std::max(1, std::min({4, nbm, (int)std::thread::hardware_concurrency()}));
+    std::vector<int> cut(nthreads + 1, nbm);
+    cut[0] = 0;
+    for (int t = 1; t < nthreads; ++t) {
+        const int target = (int)((int64_t)K * t / nthreads);
+        int bb = cut[t - 1];
+        while (bb < nbm && B.m_rowptr[bb] < target) ++bb;
+        cut[t] = bb;
     }
-    // tile lists of the SDDMM: counting pass, prefix, fill
+    auto run = [&](const std::function<void(int, int)>& body) {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nthreads; ++t) th.emplace_back(body, cut[t], cut[t + 1]);
+        body(cut[0], cut[1]);
+        for (auto& x : th) x.join();
+    };
+    // tile lists of the SDDMM: counting pass (with the fragment positions), prefix, fill
     B.m_tbase.assign(nbm + 1, 0);
     B.m_ntile_max = 0;
     for (int b = 0; b < nbm; ++b) {
@@ -523,32 +560,39 @@ inline void build_mfma_blocking(HostBlocking& B, int K, const std::vector<int32_
         B.m_tbase[b + 1] = B.m_tbase[b] + nt * MT;
     }
     B.m_tptr.assign((size_t)B.m_tbase[nbm] + 1, 0);
+    std::vector<int32_t> fill;
     for (int pass = 0; pass < 2; ++pass) {
-        std::vector<int32_t> fill;
         if (pass == 1) {
             for (size_t t = 0; t + 1 < B.m_tptr.size(); ++t) B.m_tptr[t + 1] += B.m_tptr[t];
             fill.assign(B.m_tptr.begin(), B.m_tptr.end() - 1);
             B.m_trc.assign((size_t)B.m_tptr.back(), 0);
             B.m_tepos.assign((size_t)B.m_tptr.back(), -1);
         }
-        for (int b = 0; b < nbm; ++b) {
-            for (int u = un_ptr[b]; u < un_ptr[b + 1]; ++u) loc2[un_cols[u]] = u - un_ptr[b];
-            for (int q = B.m_rowptr[b]; q < B.m_rowptr[b + 1]; ++q) {
-                const int r = B.m_order[q], rl = q - B.m_rowptr[b];
-                for (int e = indptr[r]; e < indptr[r + 1]; ++e) {
-                    if (indices[e] == r) continue;  // the diagonal comes from the exact row norms
-                    const int li = loc2[indices[e]];
-                    const int tile = B.m_tbase[b] + (li >> 5) * MT + (rl >> 5);
-                    if (pass == 0) ++B.m_tptr[(size_t)tile + 1];
-                    else {
-                        const int w = fill[tile]++;
-                        B.m_trc[w] = (uint16_t)(((rl & 31) << 5) | (li & 31));
-                        B.m_tepos[w] = e;
+        run([&, pass](int b0, int b1) {
+            std::vector<int32_t> loc2(K, -1);
+            for (int b = b0; b < b1; ++b) {
+                for (int u = un_ptr[b]; u < un_ptr[b + 1]; ++u) loc2[un_cols[u]] = u - un_ptr[b];
+                for (int q = B.m_rowptr[b]; q < B.m_rowptr[b + 1]; ++q) {
+                    const int r = B.m_order[q], rl = q - B.m_rowptr[b];
+                    for (int e = indptr[r]; e < indptr[r + 1]; ++e) {
+                        const int li = loc2[indices[e]];
+                        if (pass == 0) {
+                            const int ks = li >> 4, j = li & 7, lane = (rl & 31) + 32 * ((li >> 3) & 1), mt = rl >> 5;
+                            B.fpos[e] = ((((B.kbase[b] + ks) * MT + mt) * 2 + (j >> 2)) * 64 + lane) * 4 + (j & 3);
+                        }
+                        if (indices[e] == r) continue;  // the diagonal comes from the exact row norms
+                        const int tile = B.m_tbase[b] + (li >> 5) * MT + (rl >> 5);  // a block's tiles are its own
+                        if (pass == 0) ++B.m_tptr[(size_t)tile + 1];
+                        else {
+                            const int w = fill[tile]++;
+                            B.m_trc[w] = (uint16_t)(((rl & 31) << 5) | (li & 31));
+                            B.m_tepos[w] = e;
+                        }
                     }
                 }
+                for (int u = un_ptr[b]; u < un_ptr[b + 1]; ++u) loc2[un_cols[u]] = -1;
             }
-            for (int u = un_ptr[b]; u < un_ptr[b + 1]; ++u) loc2[un_cols[u]] = -1;
-        }
+        });
     }
     B.fits_mfma = true;
 }
