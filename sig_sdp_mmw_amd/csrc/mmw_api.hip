@@ -148,7 +148,9 @@ template <typename T> struct Solver final : mmw_solver {
         }
         const char* blk_env = getenv("MMW_BLOCKING");
         const bool start_blk = !host_only && !(blk_env && blk_env[0] == '0');
+        double t_struct = 0.0;
         std::string err = build_pattern(H, K_, Z_, Sp, Si, Sx, Qp, Qi, Qx, h, [&]() {
+            t_struct = tnow();
             if (start_blk) blk_thread = std::thread([this]() { host_blockings(); });
         });
         if (!err.empty() && blk_thread.joinable()) blk_thread.join();
@@ -226,7 +228,7 @@ template <typename T> struct Solver final : mmw_solver {
         const double t_2 = tnow();
         MMW_TRY(setup_blocking());
         const double t_3 = tnow();
-        if (verbose) fprintf(stderr, "[create] pattern %.1f ms, uploads+alloc %.1f ms, blocking %.1f ms\n", (t_1 - t_0) * 1e3, (t_2 - t_1) * 1e3, (t_3 - t_2) * 1e3);
+        if (verbose) fprintf(stderr, "[create] pattern %.1f ms (structure after %.1f), uploads+alloc %.1f ms, blocking %.1f ms\n", (t_1 - t_0) * 1e3, (t_struct - t_0) * 1e3, (t_2 - t_1) * 1e3, (t_3 - t_2) * 1e3);
         size_t big = std::max(std::max(nnz, C), eng.bs);
         MMW_TRY(out64.alloc(big));
         MMW_TRY(stage64.alloc((size_t)K * D));
