@@ -1157,7 +1157,7 @@ int expm_apply_impl(int device, int method, int max_order, double tol, int32_t K
 extern "C" {
 
 const char* mmw_last_error(void) { return last_error_ref().c_str(); }
-int mmw_version(void) { return 200; }
+int mmw_version(void) { return 210; }
 int mmw_device_count(int* n) {
     if (!n) return fail(MMW_ERR_ARG, "null pointer");
     int c = 0;
