@@ -872,6 +872,27 @@ __global__ __launch_bounds__(BLOCK) void k_refrag(size_t n, const T* __restrict_
     for (size_t e = (size_t)blockIdx.x * BLOCK + threadIdx.x; e < n; e += (size_t)gridDim.x * BLOCK) afrag[fpos[e]] = split_bf16((float)lval[e]);
 }
 // xavg += xval over the whole pattern (the running sum of X; coalesced, 12 bytes per stored entry)
+// snapshot / restore of the iterate in one launch: six value arrays (blockIdx.y) and the plan
+template <typename T> struct CopySet {
+    T* dst[6];
+    const T* src[6];
+    size_t n[6];
+    ExpmPlan* plan_dst;
+    const ExpmPlan* plan_src;
+};
+template <typename T> __global__ __launch_bounds__(BLOCK) void k_copy_state(CopySet<T> c) {
+    const int seg = blockIdx.y;
+    const T* __restrict__ s = c.src[seg];
+    T* __restrict__ d = c.dst[seg];
+    const size_t n = c.n[seg];
+    for (size_t o = (size_t)blockIdx.x * BLOCK + threadIdx.x; o < n; o += (size_t)gridDim.x * BLOCK) d[o] = s[o];
+    if (seg == 0 && blockIdx.x == 0) {
+        static_assert(sizeof(ExpmPlan) % 4 == 0, "plan copied as words");
+        const unsigned* ps = reinterpret_cast<const unsigned*>(c.plan_src);
+        unsigned* pd = reinterpret_cast<unsigned*>(c.plan_dst);
+        for (int i = threadIdx.x; i < (int)(sizeof(ExpmPlan) / 4); i += BLOCK) pd[i] = ps[i];
+    }
+}
 template <typename T> __global__ __launch_bounds__(BLOCK) void k_accumulate(size_t n, const T* __restrict__ x, T* __restrict__ sum) {
     for (size_t o = (size_t)blockIdx.x * BLOCK + threadIdx.x; o < n; o += (size_t)gridDim.x * BLOCK) sum[o] += x[o];
 }

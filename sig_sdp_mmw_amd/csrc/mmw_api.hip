@@ -91,6 +91,9 @@ template <typename T> struct Solver final : mmw_solver {
     // optimistic (no per-iteration readback) batches: snapshot for the rare replay
     DevBuf<T> sn_lval, sn_xval, sn_xavg, sn_Y, sn_yavg, sn_eaccu;
     bool pending = false;
+    // the last chunk ran the shipped path to its end, was settled without a violation and nothing has touched the iterate since: the next
+    // chunk's first iteration may continue on the lagged plan and the shifted softmax instead of restarting them exactly
+    bool chain_ok = false;
     int pend_iter0 = 0, pend_n = 0, m_guess = 3;
     size_t pend_events0 = 0;  // phase-timer events recorded before the pending chunk
     uint64_t pend_seed = 0;
@@ -616,6 +619,7 @@ template <typename T> struct Solver final : mmw_solver {
         nit = nit_;
         iter = 0;
         pending = false;
+        chain_ok = false;
         if (eng.viol_d.p) MMW_TRY(eng.clear_violation());
         MMW_TRY(eng.reset_plan_history(true));
         const size_t nnz = (size_t)H.nnzL(), C = (size_t)H.C();
@@ -631,6 +635,7 @@ template <typename T> struct Solver final : mmw_solver {
         nit = nit_;
         iter = 0;
         pending = false;
+        chain_ok = false;
         m_guess = 3;
         if (eng.viol_d.p) MMW_TRY(eng.clear_violation());
         MMW_TRY(eng.reset_plan_history(false));
@@ -680,16 +685,21 @@ template <typename T> struct Solver final : mmw_solver {
 
     int copy_state(bool save) {
         const size_t nnz = (size_t)H.nnzL(), C = (size_t)H.C();
-        auto cp = [&](DevBuf<T>& snap, DevBuf<T>& live, size_t n) -> int {
-            if (!live.p || n == 0) return MMW_OK;
-            if (snap.n < n) MMW_TRY(snap.alloc(n));
-            MMW_HIP(hipMemcpyAsync(save ? snap.p : live.p, save ? live.p : snap.p, n * sizeof(T), hipMemcpyDeviceToDevice, st));
-            return MMW_OK;
-        };
-        MMW_TRY(cp(sn_lval, lval, nnz)); MMW_TRY(cp(sn_xval, xval, nnz));
-        MMW_TRY(cp(sn_xavg, xavg, nnz)); MMW_TRY(cp(sn_Y, Y, C)); MMW_TRY(cp(sn_yavg, yavg, C)); MMW_TRY(cp(sn_eaccu, e_accu, C));
+        DevBuf<T>* snap[6] = {&sn_lval, &sn_xval, &sn_xavg, &sn_Y, &sn_yavg, &sn_eaccu};
+        DevBuf<T>* live[6] = {&lval, &xval, &xavg, &Y, &yavg, &e_accu};
+        const size_t len[6] = {nnz, nnz, nnz, C, C, C};
+        CopySet<T> cs;
+        for (int i = 0; i < 6; ++i) {
+            if (snap[i]->n < len[i]) MMW_TRY(snap[i]->alloc(len[i]));
+            cs.dst[i] = save ? snap[i]->p : live[i]->p;
+            cs.src[i] = save ? live[i]->p : snap[i]->p;
+            cs.n[i] = len[i];
+        }
         if (sn_plan.n < 1) MMW_TRY(sn_plan.alloc(1));
-        MMW_HIP(hipMemcpyAsync(save ? sn_plan.p : eng.plan_d.p, save ? eng.plan_d.p : sn_plan.p, sizeof(ExpmPlan), hipMemcpyDeviceToDevice, st));
+        cs.plan_dst = save ? sn_plan.p : eng.plan_d.p;
+        cs.plan_src = save ? eng.plan_d.p : sn_plan.p;
+        hipLaunchKernelGGL((k_copy_state<T>), dim3(256, 6), dim3(BLOCK), 0, st, cs);  // one launch instead of seven copies
+        MMW_HIP(hipGetLastError());
         if (!save && lval_blk.p) lblk_stale = true;  // rebuilt from the restored values when the fp32 kernel next needs it
         if (!save && afrag.p) {  // the fragment image follows the restored values
             hipLaunchKernelGGL((k_refrag<T>), dim3(grid_elems(nnz)), dim3(BLOCK), 0, st, nnz, lval.p, b_fpos.p, afrag.p);
@@ -708,6 +718,7 @@ template <typename T> struct Solver final : mmw_solver {
             return MMW_OK;
         }
         ++replays;
+        chain_ok = false;
         MMW_TRY(eng.clear_violation());
         MMW_TRY(copy_state(false));
         iter = pend_iter0;
@@ -725,15 +736,22 @@ template <typename T> struct Solver final : mmw_solver {
         MMW_TRY(settle());
         if (iter + n > nit) return fail(MMW_ERR_STATE, "mmw_iterate: more iterations than announced to mmw_create/mmw_reset");
         const bool optimistic = randv == nullptr && n > 1 && !kt_exact() && !getenv("MMW_SYNC_PLAN");  // profiling mode 1 counts exact launches
-        if (!optimistic) return iterate_impl(n, randv, seed, false);
+        if (!optimistic) {
+            chain_ok = false;
+            return iterate_impl(n, randv, seed, false);
+        }
         // Chunks enqueued without plan readbacks.  Each chunk starts from a device snapshot; before the next one starts the
         // plan of the previous is looked at (one sync): a chunk that needed more steps than were launched is restored and
         // replayed with per-iteration readback, and the launch order follows the device.  The last chunk is settled by the
-        // next call.  Chunks are short while L still grows fast (its norm is proportional to the iteration count).
+        // next call.  Chunks are short while L still grows fast (its norm is proportional to the iteration count): half as many iterations as have
+        // been done (4 ... 32); as many as have been done (8 ... 32) while one Lanczos step is accepted with a factor 2 to spare.
         int left = n;
         while (left > 0) {
             MMW_TRY(settle());
-            const int chunk = std::min(left, std::max(4, std::min(32, (int)iter / 2)));
+            // ... or as many as the last settled plan's estimate leaves room for (room_iterations)
+            int cap = lagged_ok() ? std::max(8, std::min(32, (int)iter)) : std::max(4, std::min(32, (int)iter / 2));
+            if (chain_ok && iter >= 4) cap = std::max(cap, std::min(32, room_iterations()));
+            const int chunk = std::min(left, cap);
             MMW_TRY(copy_state(true));
             pend_iter0 = iter; pend_n = chunk; pend_seed = seed; pend_events0 = events.size();
             MMW_TRY(iterate_impl(chunk, nullptr, seed, chunk > 1));
@@ -756,6 +774,27 @@ template <typename T> struct Solver final : mmw_solver {
         }
         if (p.m_eff >= p.m_apriori) spare = 0;  // the a-priori order is never exceeded
         return std::min(eng.max_order, p.m_eff + spare);
+    }
+    // How many more iterations one Lanczos step should stay accepted: its error estimate grows about quadratically with the norm of
+    // L, which grows linearly with the iteration count, so est(t + c) ~ est(t) ((t + c) / t)^2 <= tol gives c <= t (sqrt(tol / est) - 1);
+    // half of that.  0 unless the last plan read back stopped after one step.
+    int room_iterations() const {
+        const ExpmPlan& p = eng.last;
+        if (!p.apost || p.m_eff != 1) return 0;
+        union { unsigned u; float f; } e;
+        e.u = p.conv[1];
+        if (!((double)e.f > 0.0)) return 32;
+        const double c = 0.5 * (double)iter * (std::sqrt(p.tol / (double)e.f) - 1.0);
+        return c > 32.0 ? 32 : (c < 0.0 ? 0 : (int)c);
+    }
+    // the last plan read back accepted ONE Lanczos step with a factor 8 to spare (where the order is already rising -- the graphs
+    // without locality -- a long chunk launched with too few stages is a long replay: measured 5 187 -> 2 686 it/s at er-5pct-2k)
+    bool plan_has_room() const {
+        const ExpmPlan& p = eng.last;
+        if (!p.apost || p.m_eff != 1) return false;
+        union { unsigned u; float f; } e;
+        e.u = p.conv[1];
+        return (double)e.f <= p.tol / 8.0;
     }
     // Lagged planning pays where one Lanczos step is accepted with room to spare (its extrapolated norm bound is ~1/t larger than
     // the exact one, which must not cost a second product: on graphs without locality a product is 10x the two kernels saved).
@@ -786,6 +825,11 @@ template <typename T> struct Solver final : mmw_solver {
         const int Dpad = eng.lay.Dpad;
         int m_launch = optimistic ? m_guess : 0;
         const bool lag_chunk = optimistic && lagged_ok();  // from the plan the last settled chunk ended on
+        const bool chain = optimistic && chain_ok;          // this chunk continues the previous one (see chain_ok)
+        chain_ok = false;
+        // the plan is chained only while a single step is accepted with a factor 8 to spare: near a change of order an exact plan at
+        // the start of every chunk keeps the a-priori order down (er-1pct: 5 127 it/s with it, 4 495 without)
+        const bool chain_plan = chain && plan_has_room();
         bool xavg_deferred = false;
         // drawing the next sketch in extra workgroups of the SDDMM launch paid off with 8-wave SDDMM workgroups (+3.7 %); with
         // 16-wave ones (two per CU, every wave slot taken) it costs 1.5 %, so it is opt-in
@@ -797,10 +841,10 @@ template <typename T> struct Solver final : mmw_solver {
             // ---- DUAL
             MMW_TRY(kt.begin(KT_DUAL));
             hipLaunchKernelGGL((k_dual_rows<T>), dim3(gr), dim3(BLOCK), 0, st, P, xval.p, rsum.p, e_this.p);
-            // Lagged planning inside a chunk (not its first iteration, which plans exactly): k_dual_h also takes the row sums of the
+            // Lagged planning inside a chunk (not the first iteration of a run, a replay or after a change of the iterate, which plan exactly): k_dual_h also takes the row sums of the
             // L it walks over anyway -- last iteration's -- and one extra workgroup of k_softmax_b turns them into this iteration's plan
             // (extrapolated bounds, checked by the next plan): k_rowsums + k_plan leave the critical path.
-            const bool lagged_it = optimistic && it > 0 && eng.method == MMW_EXPM_LANCZOS && lag_chunk;
+            const bool lagged_it = optimistic && (it > 0 || chain_plan) && eng.method == MMW_EXPM_LANCZOS && lag_chunk;
             PlanArgs pa;
             if (lagged_it) {
                 pa.plan = eng.plan_d.p; pa.part = eng.row_part.p; pa.viol = eng.viol_d.p; pa.tol = eng.tol; pa.K = K; pa.method = eng.method;
@@ -809,7 +853,7 @@ template <typename T> struct Solver final : mmw_solver {
             // Inside a chunk (not its first iteration) the softmax rides in k_dual_h, shifted by the previous iteration's maximum
             // instead of this one's: one small workgroup then folds the sums, and the LOSS pass normalises where it reads
             // (kernels_loop.h, k_dual_h / k_dual_scal).  Two launches of the dependent chain fewer.
-            const bool fused_dual = optimistic && it > 0 && fuse_dual;
+            const bool fused_dual = optimistic && (it > 0 || chain) && fuse_dual;
             if (fused_dual) {
                 if (yun.n < (size_t)C) MMW_TRY(yun.alloc((size_t)C));
                 hipLaunchKernelGGL((k_dual_h<T>), dim3(gr), dim3(BLOCK), 0, st, P, rsum.p, e_this.p, e_accu.p, eta, max_part.p,
@@ -970,6 +1014,9 @@ template <typename T> struct Solver final : mmw_solver {
             hipLaunchKernelGGL(k_plan_verify, dim3(1), dim3(PLAN_THREADS), 0, st, K, eng.row_part.p, eng.nwide, eng.plan_d.p, eng.viol_d.p, iter - 1);
             MMW_HIP(hipGetLastError());
         }
+        // until settle() finds a violation or something touches the iterate.  A handle that has had to replay a chunk keeps restarting
+        // its chunks exactly (measured on er-1pct, whose order rises during the run: 5 100 it/s so, 4 500 chained)
+        chain_ok = optimistic && n > 1 && replays == 0 && !getenv("MMW_NO_CHUNK_CHAIN");
         return MMW_OK;
     }
     int sync() override {
