@@ -266,17 +266,23 @@ def main():
 
     # ---- warmup, then the timed region: exactly `steps` iterations (of every instance)
     run_steps(args.warmup)
+    for s in solvers:
+        s.read(_lib.F_E_MAX)  # the read-back of the timed region's objective record, once untimed (first launch of its kernel)
     barrier()
     t0 = time.perf_counter()
     run_steps(args.steps)
     # per-instance objective record, gathered to every rank (RCCL all_gather over xGMI, 48 B per instance)
     wall_us = (time.perf_counter() - t0) * 1e6
-    recs = [[i, Zi, 0.0, float(np.max(s.read(_lib.F_E_THIS))), args.steps, wall_us] for i, Zi, s in zip(mine, Zs, solvers)]
+    _tA = time.perf_counter()
+    recs = [[i, Zi, 0.0, float(s.read(_lib.F_E_MAX)[0]), args.steps, wall_us] for i, Zi, s in zip(mine, Zs, solvers)]  # max_c e_c(X), reduced on the device
     table = sharding.gather_records(recs, n_inst, rank, world, dist=dist, device=coll_dev if dist is not None else None)
     assert table.shape[0] == n_inst, table.shape
+    _tB = time.perf_counter()
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
+    if os.environ.get('BENCH_DEBUG'):
+        print('[bench] loop %.0f us, records %.0f us, barrier %.0f us' % ((_tA - t0) * 1e6, (_tB - _tA) * 1e6, (t1 - _tB) * 1e6), file=sys.stderr)
     if dist is not None:
         tt = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -716,4 +716,12 @@ __global__ __launch_bounds__(BLOCK) void k_max_reduce(int n, const double* __res
     m = block_max(m, sh);
     if (threadIdx.x == 0) out[0] = m;
 }
+// out[0] = max_i a[i] (one workgroup; the objective record of a solve)
+template <typename T> __global__ __launch_bounds__(1024) void k_max_of(size_t n, const T* __restrict__ a, double* __restrict__ out) {
+    __shared__ double sh[16];
+    double m = -1e300;
+    for (size_t i = threadIdx.x; i < n; i += 1024) m = (double)a[i] > m ? (double)a[i] : m;
+    m = block_max(m, sh);
+    if (threadIdx.x == 0) out[0] = m;
+}
 }  // namespace mmw

@@ -1064,6 +1064,12 @@ template <typename T> struct Solver final : mmw_solver {
             case MMW_F_Y: return export_T(Y.p, C, out, n);
             case MMW_F_E_ACCU: return export_T(e_accu.p, C, out, n);
             case MMW_F_E_THIS: return export_T(e_this.p, C, out, n);
+            case MMW_F_E_MAX: {
+                if (n != 1) return fail(MMW_ERR_ARG, "the maximum violation is one number");
+                hipLaunchKernelGGL((k_max_of<T>), dim3(1), dim3(1024), 0, st, C, e_this.p, out64.p);
+                MMW_HIP(hipGetLastError());
+                return copy_d2h(out, out64.p, sizeof(double), st);
+            }
             case MMW_F_LVAL: return export_T(lval.p, nnz, out, n);
             case MMW_F_XVAL: return export_T(xval.p, nnz, out, n);
             case MMW_F_XAVG: return export_T(xavg.p, nnz, out, n);

@@ -255,3 +255,12 @@ def test_speculative_search_reaches_a_feasible_colouring_like_the_sequential_one
     assert abs(res[True][0] - res[False][0]) <= 1
     assert res[True][1] <= res[False][1] + 1
     assert res[True][2] is not None and res[False][2] is None
+
+
+
+def test_max_violation_field_is_the_maximum_of_e_this():
+    state = journal_graph(8, 75e-4, seed=2)
+    a = _lib.Solver(10, state, 6, 0.05, dtype=_lib.F32)
+    a.iterate(6, None, seed=4)
+    assert a.read(_lib.F_E_MAX)[0] == np.max(a.read(_lib.F_E_THIS))
+    a.close()
