@@ -94,6 +94,7 @@ template <typename T> struct Solver final : mmw_solver {
     // the last chunk ran the shipped path to its end, was settled without a violation and nothing has touched the iterate since: the next
     // chunk's first iteration may continue on the lagged plan and the shifted softmax instead of restarting them exactly
     bool chain_ok = false;
+    bool plan_seen = false;  // eng.last holds a plan read back in this run (settle)
     int pend_iter0 = 0, pend_n = 0, m_guess = 3;
     size_t pend_events0 = 0;  // phase-timer events recorded before the pending chunk
     uint64_t pend_seed = 0;
@@ -636,6 +637,7 @@ template <typename T> struct Solver final : mmw_solver {
         iter = 0;
         pending = false;
         chain_ok = false;
+        plan_seen = false;
         m_guess = 3;
         if (eng.viol_d.p) MMW_TRY(eng.clear_violation());
         MMW_TRY(eng.reset_plan_history(false));
@@ -714,6 +716,7 @@ template <typename T> struct Solver final : mmw_solver {
         int viol = 0;
         MMW_TRY(eng.fetch_plan(&viol));
         if (!viol) {
+            plan_seen = true;
             m_guess = next_launch_order();
             return MMW_OK;
         }
@@ -752,6 +755,7 @@ template <typename T> struct Solver final : mmw_solver {
             int cap = lagged_ok() ? std::max(8, std::min(32, (int)iter)) : std::max(4, std::min(32, (int)iter / 2));
             if (chain_ok && iter >= 4) cap = std::max(cap, std::min(32, room_iterations()));
             const int chunk = std::min(left, cap);
+            if (plan_seen) m_guess = next_launch_order(chunk);  // before the first readback of a run: the default set by reset()
             MMW_TRY(copy_state(true));
             pend_iter0 = iter; pend_n = chunk; pend_seed = seed; pend_events0 = events.size();
             MMW_TRY(iterate_impl(chunk, nullptr, seed, chunk > 1));
@@ -763,14 +767,18 @@ template <typename T> struct Solver final : mmw_solver {
     // Steps to launch without reading the plan back: what the last application used, plus one spare step unless its
     // estimate met the tolerance with a factor 8 to spare (L grows by a fraction of itself per iteration; the plan is looked
     // at every 16 iterations; a batch that needs more anyway is replayed from its snapshot).
-    int next_launch_order() const {
+    // `ahead`: iterations the launch order has to hold for (the coming chunk).  The estimate after m steps grows like ||L||^(2m) and
+    // ||L|| like the iteration count: no spare step only if the estimate, grown over the chunk, still meets the tolerance with a
+    // factor 2 (and never without the factor 8 at the moment of the readback).
+    int next_launch_order(int ahead = 0) const {
         const ExpmPlan& p = eng.last;
         if (p.m_eff <= 0) return std::min(eng.max_order, p.m + 1);
         int spare = 1;
         if (p.apost && p.m_eff >= 1 && p.m_eff <= MAX_ORDER) {
             union { unsigned u; float f; } e;
             e.u = p.conv[p.m_eff];
-            if ((double)e.f <= p.tol / 8.0) spare = 0;
+            const double grow = std::pow((double)(iter + ahead + 1) / (double)std::max(iter, 1), 2.0 * p.m_eff);
+            if ((double)e.f <= p.tol / 8.0 && (double)e.f * grow <= p.tol / 2.0) spare = 0;
         }
         if (p.m_eff >= p.m_apriori) spare = 0;  // the a-priori order is never exceeded
         return std::min(eng.max_order, p.m_eff + spare);
