@@ -309,8 +309,26 @@ template <typename T> struct Factorizer {
     // V <- V * F twice with F from the Gram matrix: Cholesky-QR (cheap) and, when the block is too
     // ill-conditioned for it, the eigen-based factor D Q Lambda^{-1/2}; columns orthonormal to rounding
     int orthonormalise(int b, int ld, DevBuf<T>& A, DevBuf<T>& B, double eps) {
+        // tolerated deviation from the identity for the one-term form of the second pass: its result is off by 3/8 ||E||^2
+        const double ns_max = sizeof(T) == 4 ? 1.6e-3 : 5e-7;
+        static const bool ns_on = getenv("MMW_FACTOR_NO_NS") == nullptr;
         for (int pass = 0; pass < 2; ++pass) {
             MMW_TRY(dw.gram(K, b, ld, A.p, A.p, true));
+            if (pass == 1 && ns_on) {
+                // After the first pass G = I + E with a small E: V (I - E/2) is orthonormal to 3/8 ||E||^2 -- one small kernel and a
+                // tall GEMM instead of a Cholesky factorisation (b / 32 dependent panel steps) and a row substitution.
+                double dev2 = 0.0;
+                hipLaunchKernelGGL(k_dev_from_identity, dim3(1), dim3(1024), 0, st, b, dw.G.p, dw.off.p);
+                MMW_HIP(hipMemcpyAsync(&dev2, dw.off.p, sizeof(double), hipMemcpyDeviceToHost, st));
+                MMW_HIP(hipStreamSynchronize(st));
+                if (std::sqrt(dev2) <= ns_max) {
+                    hipLaunchKernelGGL(k_ns_first, dim3(grid_elems((size_t)b * b)), dim3(BLOCK), 0, st, b, dw.G.p, dw.Q2.p);
+                    MMW_HIP(hipMemsetAsync(B.p, 0, (size_t)K * ld * sizeof(T), st));
+                    MMW_TRY(dw.gemm(K, b, b, ld, A.p, dw.Q2.p, b, B.p));
+                    std::swap(A.p, B.p);
+                    continue;
+                }
+            }
             bool ok = false;
             MMW_TRY(dw.chol_factor(b, &ok));
             if (!ok) {

@@ -716,6 +716,24 @@ __global__ __launch_bounds__(BLOCK) void k_max_reduce(int n, const double* __res
     m = block_max(m, sh);
     if (threadIdx.x == 0) out[0] = m;
 }
+// ---- second pass of the orthonormalisation when the block is already nearly orthonormal: G = V^T V = I + E with a small E, and
+// (I + E)^{-1/2} = I - E/2 + O(E^2).  out[0] = ||G - I||_F^2 (one workgroup); M = 1.5 I - 0.5 G.
+__global__ __launch_bounds__(1024) void k_dev_from_identity(int b, const double* __restrict__ G, double* __restrict__ out) {
+    __shared__ double sh[16];
+    double s = 0.0;
+    for (int i = threadIdx.x >> 6; i < b; i += 16) {
+        const double* row = G + (size_t)i * b;
+        for (int j = threadIdx.x & 63; j < b; j += WAVE) {
+            const double e = row[j] - (i == j ? 1.0 : 0.0);
+            s += e * e;
+        }
+    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) out[0] = s;
+}
+__global__ __launch_bounds__(BLOCK) void k_ns_first(int b, const double* __restrict__ G, double* __restrict__ M) {
+    for (int o = blockIdx.x * BLOCK + threadIdx.x; o < b * b; o += gridDim.x * BLOCK) M[o] = ((o / b == o % b) ? 1.5 : 0.0) - 0.5 * G[o];
+}
 // out[0] = max_i a[i] (one workgroup; the objective record of a solve)
 template <typename T> __global__ __launch_bounds__(1024) void k_max_of(size_t n, const T* __restrict__ a, double* __restrict__ out) {
     __shared__ double sh[16];
