@@ -386,49 +386,42 @@ __global__ __launch_bounds__(BLOCK) void k_bj_apply(int M, int P, int r, const d
         if (!qpart) Ra[k][l] = R[(size_t)a * BJ_N2 * BJ_N2 + o];
     }
     __syncthreads();
-    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-    double acc[4][4];
+    // 64 x 64 x 64 products on the fp64 matrix cores: wave w owns output rows 16 w .. 16 w + 15, four 16 x 16 column tiles
+    // (operand / accumulator layout of v_mfma_f64_16x16x4_f64 as in k_gram)
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    d4 acc[4];
     if (!qpart) {  // tmp = Ra^T T, written back over T
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int t = 0; t < 4; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+        for (int kk = 0; kk < BJ_N2; kk += 4) {
+            const double av = Ra[kk + lk][wib * 16 + li];
 #pragma unroll
-            for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
-        for (int k = 0; k < BJ_N2; ++k) {
-            double av[4], bv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { av[u] = Ra[k][4 * ty + u]; bv[u] = T[k][4 * tx + u]; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) acc[u][v] += av[u] * bv[v];
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, T[kk + lk][t * 16 + li], acc[t], 0, 0, 0);
         }
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) T[4 * ty + u][4 * tx + v] = acc[u][v];
+            for (int q = 0; q < 4; ++q) T[wib * 16 + lk + 4 * q][t * 16 + li] = acc[t][q];
         __syncthreads();
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int t = 0; t < 4; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int kk = 0; kk < BJ_N2; kk += 4) {
+        const double av = T[wib * 16 + li][kk + lk];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
-    for (int k = 0; k < BJ_N2; ++k) {
-        double av[4], bv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { av[u] = T[4 * ty + u][k]; bv[u] = Rc[k][4 * tx + u]; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) acc[u][v] += av[u] * bv[v];
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Rc[kk + lk][t * 16 + li], acc[t], 0, 0, 0);
     }
     double* dst = qpart ? Qout : Hout;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int k = 4 * ty + u;
+    for (int q = 0; q < 4; ++q) {
+        const int k = wib * 16 + lk + 4 * q;
         const int gr = qpart ? BJ_N2 * x + k : bj_index(Ia, Ja, k);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) dst[(size_t)gr * P + bj_index(Ic, Jc, 4 * tx + v)] = acc[u][v];
+        for (int t = 0; t < 4; ++t) dst[(size_t)gr * P + bj_index(Ic, Jc, t * 16 + li)] = acc[t][q];
     }
 }
 constexpr int BJ_APPLY_LDS = 3 * BJ_N2 * (BJ_N2 + 1) * (int)sizeof(double);
