@@ -145,7 +145,7 @@ template <typename T> struct DenseWork {
             MMW_HIP(hipStreamSynchronize(st));
             if (!(std::sqrt(h_off[0]) > rel_tol * h_off[1] * std::sqrt((double)b)) || b < 2) break;
             for (int r = 0; r < M - 1; ++r) {
-                hipLaunchKernelGGL(k_bj_solve, dim3(half), dim3(1024), 0, st, M, P, r, (r == 0 || all_full) ? 1 : 0, bjH[cur].p, bjR.p);
+                hipLaunchKernelGGL(k_bj_solve, dim3(half), dim3(1024), 0, st, M, P, r, (r == 0 || all_full) ? 1 : 0, bjH[cur].p, bjR.p, rel_tol);
                 hipLaunchKernelGGL(k_bj_apply, dim3(half * half + (P / BJ_N2) * half), dim3(BLOCK), BJ_APPLY_LDS, st, M, P, r, bjH[cur].p,
                                    bjH[cur ^ 1].p, bjQ[cur].p, bjQ[cur ^ 1].p, bjR.p);
                 cur ^= 1;

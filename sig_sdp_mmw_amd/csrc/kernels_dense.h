@@ -305,8 +305,10 @@ __device__ __forceinline__ void bj_pair(bool full, int rr, int i, int& p, int& q
     if (full) jacobi_pair(BJ_N2, rr, i, p, q);
     else { p = i; q = BJ_NB + ((i + rr) & (BJ_NB - 1)); }
 }
-__global__ __launch_bounds__(1024) void k_bj_solve(int M, int P, int r, int full, const double* __restrict__ Hin, double* __restrict__ R /* [M/2][64][64] */) {
+__global__ __launch_bounds__(1024) void k_bj_solve(int M, int P, int r, int full, const double* __restrict__ Hin, double* __restrict__ R /* [M/2][64][64] */,
+                                                   double skip_tol) {
     __shared__ double S[BJ_N2][BJ_N2 + 1], Qm[BJ_N2][BJ_N2 + 1], cs[BJ_N2];
+    __shared__ double red[2][16];
     int I, J;
     jacobi_pair(M, r, (int)blockIdx.x, I, J);
     for (int o = threadIdx.x; o < BJ_N2 * BJ_N2; o += 1024) {
@@ -315,6 +317,27 @@ __global__ __launch_bounds__(1024) void k_bj_solve(int M, int P, int r, int full
         Qm[k][l] = k == l ? 1.0 : 0.0;
     }
     __syncthreads();
+    {   // A pair whose off-diagonal part (the part this meeting rotates) is already below the solver's tolerance, relative to its own
+        // diagonal, is left alone: in the last sweeps that is most pairs, and its rounds are the cost of a block round.
+        double so = 0.0, dm = 0.0;
+        for (int o = threadIdx.x; o < BJ_N2 * BJ_N2; o += 1024) {
+            const int k = o >> 6, l = o & 63;
+            const double v = S[k][l];
+            if (k == l) dm = fabs(v) > dm ? fabs(v) : dm;
+            else if (full || ((k < BJ_NB) != (l < BJ_NB))) so += v * v;
+        }
+        so = wave_sum(so);
+        dm = wave_max(dm);
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = so; red[1][threadIdx.x >> 6] = dm; }
+        __syncthreads();
+        so = 0.0; dm = 0.0;
+        for (int w = 0; w < 16; ++w) { so += red[0][w]; dm = red[1][w] > dm ? red[1][w] : dm; }
+        if (!(sqrt(so) > skip_tol * dm)) {
+            double* out = R + (size_t)blockIdx.x * BJ_N2 * BJ_N2;
+            for (int o = threadIdx.x; o < BJ_N2 * BJ_N2; o += 1024) out[o] = (o >> 6) == (o & 63) ? 1.0 : 0.0;
+            return;
+        }
+    }
     const int i = threadIdx.x >> 5, j = threadIdx.x & 31;
     const int nrounds = full ? BJ_N2 - 1 : BJ_NB;
     for (int rr = 0; rr < nrounds; ++rr) {
