@@ -264,3 +264,26 @@ def test_max_violation_field_is_the_maximum_of_e_this():
     a.iterate(6, None, seed=4)
     assert a.read(_lib.F_E_MAX)[0] == np.max(a.read(_lib.F_E_THIS))
     a.close()
+
+
+@pytest.mark.parametrize("dtype,tol", [(_lib.F32, 2e-5), (_lib.F64, 1e-9)])
+def test_chained_chunks_give_the_result_of_chunks_that_restart_exactly(dtype, tol, monkeypatch):
+    """A handle that has not replayed lets a chunk's first iteration continue on the lagged plan and the shifted softmax of the
+    previous chunk (and sizes its chunks by the room the error estimate leaves).  Several calls of different lengths, so that chunk
+    boundaries fall everywhere: same result as with chunks that restart exactly, to the tolerance of the exponential, no replay."""
+    state = journal_graph(16, 0.02, seed=4)
+    Z, nit = 24, 90
+    def run():
+        a = _lib.Solver(Z, state, nit, 0.04, dtype=dtype)
+        for n in (5, 20, 3, 40, 22):
+            a.iterate(n, None, seed=9)
+        out = [a.read(f) for f in FIELDS]
+        replays = a.read(_lib.F_BLOCKING)[3]
+        a.close()
+        return out, replays
+    got, replays = run()
+    assert replays == 0
+    monkeypatch.setenv("MMW_NO_CHUNK_CHAIN", "1")
+    ref, _ = run()
+    for f, x, y in zip(FIELDS, got, ref):
+        assert relerr(x, y) < tol, f
