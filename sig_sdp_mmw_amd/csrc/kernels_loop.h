@@ -90,6 +90,10 @@ __global__ __launch_bounds__(BLOCK) void k_dual_h(PatternDev<T> P, const T* __re
     const int baseH = K + P.E_asso;
     for (int row = blockIdx.x * WAVES_PER_BLOCK + wib; row < K; row += gridDim.x * WAVES_PER_BLOCK) {
         double s = 0.0, la = 0.0, ld = 0.0;
+        // the row's own scalars do not depend on the sum: requested up front, they arrive under the entries' loads instead of adding
+        // a memory round trip to lane 0's tail
+        const double r_hmax = (double)P.h_max[row], r_ssum = (double)P.S_sum[row], r_invn = (double)P.inv_norm_H[row];
+        const double r_eacc = (double)e_accu[baseH + row], r_cH = mref ? (double)P.cH[row] : 0.0;
         for (int e = P.indptr[row] + lane; e < P.indptr[row + 1]; e += WAVE) {
             const double w = (double)P.sab[e];
             const int c = P.col[e];
@@ -111,19 +115,18 @@ __global__ __launch_bounds__(BLOCK) void k_dual_h(PatternDev<T> P, const T* __re
             }
         }
         if (lane == 0) {
-            const double eh = (s * (double)(Z - 1) / (double)Z - ((double)P.h_max[row] - (1.0 / (double)Z) * (double)P.S_sum[row])) *
-                              (double)P.inv_norm_H[row];  // mmw.py:134
+            const double eh = (s * (double)(Z - 1) / (double)Z - (r_hmax - (1.0 / (double)Z) * r_ssum)) * r_invn;  // mmw.py:134
             e_this[baseH + row] = (T)eh;
-            const T a = (T)((double)e_accu[baseH + row] + (double)(T)eh * eta);
+            const T a = (T)(r_eacc + (double)(T)eh * eta);
             e_accu[baseH + row] = a;
             best = (double)a > best ? (double)a : best;
             if (mref) {
                 const T ex = (T)exp((double)a - m0);
-                const double wn = (double)ex * (double)P.inv_norm_H[row];
+                const double wn = (double)ex * r_invn;
                 Yun[baseH + row] = ex;
                 wun[row] = (T)wn;
                 sH += (double)ex;
-                sW += (double)P.cH[row] * wn;
+                sW += r_cH * wn;
             }
         }
     }
