@@ -73,3 +73,54 @@ def test_dropin_overlay_resolves_to_this_solver():
     env = dict(os.environ, MMW_DTYPE="f32", MMW_RNG="device", MMW_EXPM_TOL="1e-6", MMW_WARM_START="1")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr
+
+
+class Threshold:
+    """Deterministic stand-in with the protocol the speculative search needs: a slot count is feasible iff it is at least `zmin`;
+    every solve is recorded (thread-safe append), `sibling()` shares the record."""
+    rng = "device"
+
+    def __init__(self, zmin, log=None):
+        self.zmin = zmin
+        self.log = [] if log is None else log
+        self.closed = False
+
+    def sibling(self):
+        return Threshold(self.zmin, self.log)
+
+    def prepare(self, Z, state):
+        self.log.append(("prepare", Z))
+
+    def run_with_state(self, it, Z, state):
+        self.log.append(("solve", Z))
+        return True, np.full((state[0].shape[0], 2), float(Z))
+
+    def rounding(self, Z, gX, state):
+        assert gX[0, 0] == float(Z)  # the rounding gets the factor of the slot count it is asked about
+        return np.zeros(state[0].shape[0]), Z, (0 if Z >= self.zmin else self.zmin - Z)
+
+    def close(self):
+        self.closed = True
+
+
+@pytest.mark.parametrize("zmin", [2, 3, 7, 11, 12, 13, 20])
+def test_speculative_search_decides_like_the_sequential_one(zmin):
+    """binary_search.speculate: probes solved ahead are used only when the search arrives at them; the deciding sequence of
+    (left, right, mid, remainder) rows is the sequential search's, row for row."""
+    g = load_golden("bs_run")
+    state = state_from(g, "env75_")
+    rows = {}
+    for spec in (False, True):
+        bs = binary_search_relaxation()
+        bs.verbose = False
+        bs.speculate = spec
+        alg = Threshold(zmin)
+        bs.feasibility_check_alg = alg
+        z_vec, Z, rem = bs.run(state)
+        assert rem == 0 and Z >= zmin
+        rows[spec] = bs.LOGGED_NP_DATA["bs_search_per_it"][:, 3:8]  # left, right, mid, Z, rem
+        if spec:
+            solved = [z for kind, z in alg.log if kind == "solve"]
+            assert len(solved) >= rows[spec].shape[0]  # every deciding probe was solved, some more were solved ahead
+            assert "bs_speculation" in bs.LOGGED_NP_DATA
+    assert np.array_equal(rows[True], rows[False])
