@@ -33,6 +33,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -180,6 +181,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="journal-1pct", choices=sorted(WORKLOADS))
     ap.add_argument("--instances-per-gpu", type=int, default=1, help="resident handles per rank, iterations enqueued round-robin (configs[3]: 8)")
+    ap.add_argument("--instance-threads", action="store_true", help="with --instances-per-gpu M: one host thread per instance instead of round-robin calls")
     ap.add_argument("--expm", default="lanczos", choices=["lanczos", "taylor"])
     ap.add_argument("--dtype", default=None, choices=["f32", "f64"])
     ap.add_argument("--eta", type=float, default=0.04)
@@ -256,13 +258,25 @@ def main():
         their streams overlap on the device (every mmw_iterate returns once its work is enqueued)."""
         if len(solvers) == 1:
             solvers[0].iterate(n, None, seeds[0])
+            solvers[0].sync()
+        elif args.instance_threads:
+            # one host thread per resident instance: the launches of a step are ~20 small kernels, and one thread enqueues ~10 k
+            # iterations per second whatever the GPU could overlap (the library calls release the GIL)
+            def one(s, sd):
+                s.iterate(n, None, sd)
+                s.sync()
+            ths = [threading.Thread(target=one, args=(s, sd)) for s, sd in zip(solvers, seeds)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
         else:
             chunk = 16
             for s0 in range(0, n, chunk):
                 for s, sd in zip(solvers, seeds):
                     s.iterate(min(chunk, n - s0), None, sd)
-        for s in solvers:
-            s.sync()
+            for s in solvers:
+                s.sync()
 
     # ---- warmup, then the timed region: exactly `steps` iterations (of every instance)
     run_steps(args.warmup)
