@@ -16,7 +16,7 @@ EXPM_LANCZOS, EXPM_TAYLOR = 0, 1
 
 # enum mmw_field / mmw_ifield
 F_Y, F_E_ACCU, F_E_THIS, F_LVAL, F_XVAL, F_XAVG, F_YAVG, F_XHALF, F_SKETCH = range(9)
-F_S_SUM, F_NORM_H, F_ST_DATA, F_PHASE_US, F_EXPM_INFO, F_FACTOR, F_KERNEL_US, F_BLOCKING, F_SPMM_KIND, F_E_MAX = range(9, 19)
+F_S_SUM, F_NORM_H, F_ST_DATA, F_PHASE_US, F_EXPM_INFO, F_FACTOR, F_KERNEL_US, F_BLOCKING, F_SPMM_KIND, F_E_MAX, F_DUAL_INFO = range(9, 20)
 KERNEL_CLASSES = ["spmm", "sddmm", "dual", "loss", "krylov_vec", "sketch", "project", "greedy", "factor"]
 I_L_INDPTR, I_L_INDICES, I_ST_INDPTR, I_ST_INDICES, I_GAIN_X, I_GAIN_Y, I_ASSO_X, I_ASSO_Y, I_DIAG_POS, I_ASSO_POS = range(10)
 
@@ -231,7 +231,7 @@ class Solver:
                 n = self.K * self.D
             elif which in (F_EXPM_INFO, F_BLOCKING):
                 n = 4
-            elif which == F_SPMM_KIND:
+            elif which in (F_SPMM_KIND, F_DUAL_INFO):
                 n = 2
             elif which == F_E_MAX:
                 n = 1

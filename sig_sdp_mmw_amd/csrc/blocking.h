@@ -78,6 +78,7 @@ struct HostBlocking {
     std::vector<int32_t> m_tbase;       // [nbm+1]
     std::vector<int32_t> m_tptr;        // [tiles+1]
     std::vector<uint16_t> m_trc;        // [off-diagonal nnz]
+    std::vector<uint16_t> m_tmask;      // [tiles][64]: per lane of the 32x32 accumulator (column lane & 31, rows (v & 3) + 8 (v >> 2) + 4 (lane >> 5)) bit v set where the pattern has an off-diagonal entry
     std::vector<int32_t> m_tepos;       // [off-diagonal nnz]
     int m_ntile_max = 0;                // most union tiles of any block
     double m_reuse = 0.0;
@@ -473,6 +474,8 @@ inline void build_mfma_blocking(HostBlocking& B, int K, const std::vector<int32_
     const std::vector<int32_t>& rcm = B.rcm_cache;
     std::vector<int32_t> rank(K);
     for (int p = 0; p < K; ++p) rank[rcm[p]] = p;
+    static const int cap_env = getenv("MMW_MF_UNION_CAP") ? atoi(getenv("MMW_MF_UNION_CAP")) : 0;
+    const int union_cap = cap_env > 0 ? std::min(cap_env, MF_UNION) : MF_UNION;
     B.m_order.assign(K, -1);
     B.m_rowptr.assign(1, 0);
     std::vector<int32_t> un_ptr(1, 0), un_cols;
@@ -487,7 +490,7 @@ inline void build_mfma_blocking(HostBlocking& B, int K, const std::vector<int32_
             int fresh = 0;
             for (int e = indptr[r]; e < indptr[r + 1]; ++e)
                 if (stamp[indices[e]] != blk) ++fresh;
-            if (rows > 0 && (int)cur.size() + fresh > MF_UNION) break;
+            if (rows > 0 && (int)cur.size() + fresh > union_cap) break;
             for (int e = indptr[r]; e < indptr[r + 1]; ++e) {
                 const int c = indices[e];
                 if (stamp[c] != blk) {
@@ -567,6 +570,7 @@ inline void build_mfma_blocking(HostBlocking& B, int K, const std::vector<int32_
             fill.assign(B.m_tptr.begin(), B.m_tptr.end() - 1);
             B.m_trc.assign((size_t)B.m_tptr.back(), 0);
             B.m_tepos.assign((size_t)B.m_tptr.back(), -1);
+            B.m_tmask.assign((size_t)B.m_tbase[nbm] * 64, 0);
         }
         run([&, pass](int b0, int b1) {
             std::vector<int32_t> loc2(K, -1);
@@ -587,6 +591,8 @@ inline void build_mfma_blocking(HostBlocking& B, int K, const std::vector<int32_
                             const int w = fill[tile]++;
                             B.m_trc[w] = (uint16_t)(((rl & 31) << 5) | (li & 31));
                             B.m_tepos[w] = e;
+                            const int r5 = rl & 31;  // accumulator slot of (row r5, column li & 31): lane = column + 32 ((r5 >> 2) & 1), register (r5 & 3) + 4 (r5 >> 3)
+                            B.m_tmask[(size_t)tile * 64 + (li & 31) + 32 * ((r5 >> 2) & 1)] |= (uint16_t)(1u << ((r5 & 3) + 4 * (r5 >> 3)));
                         }
                     }
                 }
@@ -745,8 +751,15 @@ inline std::string verify_mfma_blocking(const HostBlocking& B, int K, const std:
         if (B.m_tbase[b + 1] - B.m_tbase[b] != nt * MT) return "tile count of a matrix-core block is off";
         for (int t = B.m_tbase[b]; t < B.m_tbase[b + 1]; ++t) {
             const int ut = (t - B.m_tbase[b]) / MT, mt = (t - B.m_tbase[b]) % MT;
+            int bits = 0;  // the accumulator mask of the tile marks exactly the listed entries
+            for (int l = 0; l < 64; ++l) bits += __builtin_popcount((unsigned)B.m_tmask[(size_t)t * 64 + l]);
+            if (B.m_tmask.size() < (size_t)(t + 1) * 64 || bits != B.m_tptr[t + 1] - B.m_tptr[t]) return "accumulator mask of a tile does not match its list";
             for (int w = B.m_tptr[t]; w < B.m_tptr[t + 1]; ++w, ++listed) {
                 const int e = B.m_tepos[w], rl = 32 * mt + (B.m_trc[w] >> 5), li = 32 * ut + (B.m_trc[w] & 31);
+                {
+                    const int r5 = B.m_trc[w] >> 5, c5 = B.m_trc[w] & 31;
+                    if (!((B.m_tmask[(size_t)t * 64 + c5 + 32 * ((r5 >> 2) & 1)] >> ((r5 & 3) + 4 * (r5 >> 3))) & 1)) return "accumulator mask misses a listed entry";
+                }
                 if (e < 0 || e >= nnz || seen_e[e]) return "tile list holds a bad or repeated entry";
                 seen_e[e] = 1;
                 if (rl >= d[1] || li >= nun) return "tile list entry outside its block";

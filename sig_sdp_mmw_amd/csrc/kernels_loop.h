@@ -76,7 +76,10 @@ __global__ __launch_bounds__(BLOCK) void k_dual_h(PatternDev<T> P, const T* __re
                                                   const T* __restrict__ lval = nullptr, double lscale = 0.0,
                                                   double* __restrict__ lpart = nullptr /* [3][grid], as k_rowsums */,
                                                   const double* __restrict__ mref = nullptr, T* __restrict__ Yun = nullptr,
-                                                  T* __restrict__ wun = nullptr, double* __restrict__ sum_part = nullptr /* [4][grid] */) {
+                                                  T* __restrict__ wun = nullptr, double* __restrict__ sum_part = nullptr /* [4][grid] */,
+                                                  const long long* __restrict__ rsfx = nullptr /* [K] */, const T* __restrict__ xval = nullptr) {
+    // With `rsfx` the row sums of X come from the matrix-core SDDMM (k_sddmm_mfma: 2^-40 fixed point) instead of k_dual_rows, and
+    // the D / F violations that kernel made are taken here from `xval` (mmw.py:127,131).
     // With `mref` (the maximum of e_accu one iteration ago, left in scal[4]) the pass also does softmax pass A's work with that
     // shift instead of this iteration's maximum: the softmax does not depend on the shift, and e_accu's maximum moves by
     // eta * max e per iteration, so the exponentials stay far from overflow (k_dual_scal checks exactly that).  Yun / wun get
@@ -97,7 +100,10 @@ __global__ __launch_bounds__(BLOCK) void k_dual_h(PatternDev<T> P, const T* __re
         for (int e = P.indptr[row] + lane; e < P.indptr[row + 1]; e += WAVE) {
             const double w = (double)P.sab[e];
             const int c = P.col[e];
-            if (w != 0.0) s += w * (double)rsum[c];
+            if (w != 0.0) {
+                const double rc = rsfx ? (double)rsfx[c] * (1.0 / SDM_FX) : (double)rsum[c];
+                s += w * rc;
+            }
             if (lval) {  // the pass reads these rows anyway: |L| row sums and the diagonal, like k_rowsums
                 const double v = lscale * (double)lval[e];
                 if (c == row) ld = v;
@@ -130,8 +136,14 @@ __global__ __launch_bounds__(BLOCK) void k_dual_h(PatternDev<T> P, const T* __re
             }
         }
     }
+    const double invK = 1.0 / (double)K, Zm1 = (double)(Z - 1), denF = 1.0 / ((double)K * Zm1) + 0.5;
     for (int c = blockIdx.x * BLOCK + threadIdx.x; c < baseH; c += gridDim.x * BLOCK) {
-        const T a = (T)((double)e_accu[c] + (double)e_this[c] * eta);
+        T et;
+        if (rsfx) {
+            et = c < K ? (T)(((double)xval[P.diag_pos[c]] - 1.0) / (1.0 - invK)) : (T)(((double)xval[P.asso_pos[c - K]] + 1.0 / Zm1) / denF);
+            e_this[c] = et;
+        } else et = e_this[c];
+        const T a = (T)((double)e_accu[c] + (double)et * eta);
         e_accu[c] = a;
         best = (double)a > best ? (double)a : best;
         if (mref) {
@@ -293,7 +305,8 @@ __global__ __launch_bounds__(BLOCK) void k_loss(PatternDev<T> P, const int* __re
                                                 const T* __restrict__ xval = nullptr, T* __restrict__ xavg = nullptr,
                                                 SketchArgs<T> sk = SketchArgs<T>{}, int Dpad = 0, const int* __restrict__ fpos = nullptr,
                                                 unsigned* __restrict__ afrag = nullptr, T* __restrict__ Ynorm = nullptr,
-                                                T* __restrict__ yavg = nullptr, int accumulate = 0, PlanArgs pa = PlanArgs{}) {
+                                                T* __restrict__ yavg = nullptr, int accumulate = 0, PlanArgs pa = PlanArgs{},
+                                                long long* __restrict__ rs_zero = nullptr /* [K]: row-sum totals the coming SDDMM adds to */) {
     // Ynorm != nullptr: Y and wH hold the unnormalised exponentials of the fused DUAL pass (k_dual_h, mref form) and scal[3]
     // their total; this pass divides where it uses them and writes the normalised Y (and its running sum) on the side.
     if ((int)blockIdx.x < sk.nblocks) {  // leading workgroups draw this iteration's sketch (same shape as k_sketch_rng: same bits)
@@ -317,6 +330,8 @@ __global__ __launch_bounds__(BLOCK) void k_loss(PatternDev<T> P, const int* __re
     const double dconst = -(sumYD * invK) / (1.0 - invK) + (sumYF / ((double)K * Zm1)) / cF - sumW;
     const double total = Ynorm ? scal[3] : 1.0, inv_total = 1.0 / total;
     const double gscale = (Zm1 / (double)(2 * Z)) * inv_total;
+    if (rs_zero)
+        for (int k = bid * BLOCK + threadIdx.x; k < K; k += nb * BLOCK) rs_zero[k] = 0;
     if (Ynorm)
         for (int c = bid * BLOCK + threadIdx.x; c < P.C; c += nb * BLOCK) {
             const T y = (T)((double)Y[c] / total);

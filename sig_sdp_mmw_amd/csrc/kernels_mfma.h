@@ -406,7 +406,9 @@ struct SdMfmaDev {
     const int* tptr;              // [tiles+1] entry ranges
     const unsigned short* trc;    // row in tile << 5 | column in tile
     const int* tepos;             // CSR position
+    const unsigned short* tmask;  // [tiles][64] accumulator mask of the pattern's entries (blocking.h, m_tmask)
 };
+constexpr double SDM_FX = 1099511627776.0;  // 2^40: fixed-point scale of the row sums k_sddmm_mfma hands to the DUAL phase
 constexpr int SDM_GT = 4;   // union tiles per workgroup
 constexpr int SDM_KC = 2;   // k-steps per chunk (a 128-byte line per row: 64 bytes of hi halves, 64 of lo halves)
 template <int MT> constexpr int sdm_rows() { return 32 * MT + 32 * SDM_GT; }
@@ -416,7 +418,13 @@ template <int MT> constexpr int sdm_lds_bytes() { return sdm_rows<MT>() * 4 + 2 
 template <int MT>
 __global__ __launch_bounds__(4 * MT * 64)
 void k_sddmm_mfma(MfmaDev M, SdMfmaDev S, int K, int Dpad, const char* __restrict__ Ypl, const float* __restrict__ d,
-                  const double* __restrict__ tr_part, int ntr, const int* __restrict__ diag_pos, float* __restrict__ xval) {
+                  const double* __restrict__ tr_part, int ntr, const int* __restrict__ diag_pos, float* __restrict__ xval,
+                  long long* __restrict__ rsfx = nullptr /* [K], zero at launch */) {
+    // rsfx: the DUAL phase's first step (mmw.py:133-134, the row sums of the off-diagonal X) leaves with the tiles: every wave sums
+    // its tile's pattern entries per row straight from the accumulators, the workgroup's union tiles meet in LDS, and the part of
+    // this union-tile group is added to the row's total as a 2^-40 fixed-point integer (|sum| < 2^10 for rows of <= 640 entries
+    // of magnitude <= 1): integer atomics commute, so the total does not depend on the order the workgroups arrive in.
+    // The LOSS pass of every iteration zeroes the totals (k_loss), k_dual_h reads them.
     constexpr int NW = 4 * MT, THREADS = NW * 64;
     constexpr int RA = 32 * MT, R = sdm_rows<MT>();
     constexpr int CHUNK = sdm_chunk_bytes<MT>();
@@ -456,6 +464,15 @@ void k_sddmm_mfma(MfmaDev M, SdMfmaDev S, int K, int Dpad, const char* __restric
 #pragma unroll
     for (int w = 0; w < NW; ++w) tr += sh_tr[w];
     tr /= (double)K;
+    // what the wave's tail needs of the tile lists is requested now: these dependent loads would otherwise sit behind the last product
+    int tw0 = 0, tw1 = 0;
+    unsigned mk = 0u;
+    if (ut0 + wn < ntile) {
+        const int t = S.tbase[rb] + (ut0 + wn) * MT + wm;
+        tw0 = S.tptr[t];
+        tw1 = S.tptr[t + 1];
+        if (rsfx) mk = (unsigned)S.tmask[(size_t)t * 64 + lane];
+    }
 
     // DMA pieces of this wave: piece i = wv + NW j covers rows 8 i .. 8 i + 7; lane L -> row 8 i + (L >> 3), position L & 7,
     // which holds source slot (position - (row >> 1)) & 7 of the row's 128-byte chunk line (slots 0-3 hi halves, 4-7 lo halves)
@@ -511,21 +528,37 @@ void k_sddmm_mfma(MfmaDev M, SdMfmaDev S, int K, int Dpad, const char* __restric
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mf_bf8, ah), __builtin_bit_cast(mf_bf8, bh), acc, 0, 0, 0);
         }
     }
+    static_assert(NW * 4096 + 4 * 32 * MT * 4 <= 2 * CHUNK, "tiles and row-sum parts fit into the chunk buffers");
+    float rsv[16];
+    if (rsfx) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) rsv[v] = group_sum(((mk >> v) & 1u) ? acc[v] : 0.f, 32);  // over the 32 columns of the tile
+    }
     __syncthreads();  // every wave is done with the chunk buffers: they now hold the 32 x 32 output tiles, one per wave
+    float* rsl = reinterpret_cast<float*>(bufs) + NW * 1024;  // [4 union tiles][32 MT rows] behind the tiles
+    if (rsfx && (lane & 31) == 0) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) rsl[wn * RA + 32 * wm + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5)] = rsv[v];
+    }
     float* tile = reinterpret_cast<float*>(bufs) + wv * 1024;
 #pragma unroll
     for (int v = 0; v < 16; ++v) tile[((v & 3) + 8 * (v >> 2) + 4 * h) * 32 + r] = acc[v];  // C layout: column = lane & 31
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const int ut = ut0 + wn;
-    if (ut < ntile) {
-        const int t = S.tbase[rb] + ut * MT + wm;
-        for (int w = S.tptr[t] + lane; w < S.tptr[t + 1]; w += 64) xval[S.tepos[w]] = (float)((double)tile[S.trc[w]] / tr);
+    if (rsfx) __syncthreads();  // tiles and row-sum parts of every wave
+    else {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
+    for (int w = tw0 + lane; w < tw1; w += 64) xval[S.tepos[w]] = (float)((double)tile[S.trc[w]] / tr);
     if (blockIdx.y == 0)  // the diagonal of the block's rows from the exact row norms
         for (int i = threadIdx.x; i < nrows; i += THREADS) {
             const int row = rows_l[i];
             xval[diag_pos[row]] = (float)((double)d[row] / tr);
+        }
+    if (rsfx)
+        for (int i = threadIdx.x; i < nrows; i += THREADS) {
+            const float sum4 = ((rsl[i] + rsl[RA + i]) + rsl[2 * RA + i]) + rsl[3 * RA + i];
+            const long long q = __double2ll_rn((double)sum4 / tr * SDM_FX);
+            atomicAdd(reinterpret_cast<unsigned long long*>(rsfx) + rows_l[i], (unsigned long long)q);  // integers: the order of arrival does not matter
         }
 }
 

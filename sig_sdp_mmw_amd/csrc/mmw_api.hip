@@ -84,7 +84,11 @@ template <typename T> struct Solver final : mmw_solver {
     DevBuf<int> b_kbase, b_fpos, b_mdesc, b_munfixed, b_morder;  // matrix-core SpMM: its row blocks, CSR entry -> fragment image position
     DevBuf<unsigned> afrag;          // the matrix as bf16 hi << 16 | lo words in MFMA fragment order
     DevBuf<int> b_tbase, b_tptr, b_tepos;  // matrix-core SDDMM: pattern entries by 32 x 32 output tile
-    DevBuf<unsigned short> b_trc, xh_planes;
+    DevBuf<unsigned short> b_trc, b_tmask, xh_planes;
+    DevBuf<long long> rsfx;  // [K] row sums of the off-diagonal X in 2^-40 fixed point, left by the matrix-core SDDMM (kernels_mfma.h)
+    bool rs_last = false;    // the last iteration enqueued left rsfx for the X the next one starts from
+    const bool rs_enabled = getenv("MMW_NO_SDDMM_ROWSUMS") == nullptr;
+    long long n_rs_iters = 0, n_fused_iters = 0;  // MMW_F_DUAL_INFO
     bool sddmm_mfma = false;
     size_t afrag_n = 0;
     int blocking_mode = 1;  // 1: use when profitable, 0: never
@@ -177,6 +181,10 @@ template <typename T> struct Solver final : mmw_solver {
                 build_mfma_blocking(HB, K, H.l_indptr, H.l_indices, getenv("MMW_MF_ROWS") ? atoi(getenv("MMW_MF_ROWS")) : 64);
                 fprintf(stderr, "[mmw] matrix-core blocking %.1f ms: ok %d blocks %d rows/block %.1f reuse %.2f row tiles %d k-steps %d\n", (tnow() - t1) * 1e3,
                         (int)HB.fits_mfma, HB.nbm(), (double)K / std::max(1, HB.nbm()), HB.m_reuse, HB.mfma_mt, HB.kbase.empty() ? 0 : HB.kbase.back());
+                if (getenv("MMW_HOST_BLOCKING_HIST")) {  // k-steps of every block, in launch order
+                    for (int b = 0; b < HB.nbm(); ++b) fprintf(stderr, "%d:%d ", HB.m_desc[(size_t)b * 8 + 1], HB.kbase[b + 1] - HB.kbase[b]);
+                    fprintf(stderr, "\n");
+                }
             }
             if (getenv("MMW_CHECK_BLOCKING")) {  // CPU tests: build the blocking and check its invariants
                 const BlockingLimits lim = blocking_limits<T>();
@@ -380,6 +388,8 @@ template <typename T> struct Solver final : mmw_solver {
             if (!getenv("MMW_NO_MFMA_SDDMM")) {
                 MMW_TRY(b_tbase.upload(HB.m_tbase, st)); MMW_TRY(b_tptr.upload(HB.m_tptr, st)); MMW_TRY(b_trc.upload(HB.m_trc, st));
                 MMW_TRY(b_tepos.upload(HB.m_tepos, st));
+                MMW_TRY(b_tmask.upload(HB.m_tmask, st));
+                MMW_TRY(rsfx.alloc((size_t)K));
                 sddmm_mfma = true;
             }
             if ((size_t)HB.nbm() > (size_t)MAX_PART && HB.nbm() > HB.nb()) {
@@ -839,6 +849,10 @@ template <typename T> struct Solver final : mmw_solver {
         // the start of every chunk keeps the a-priori order down (er-1pct: 5 127 it/s with it, 4 495 without)
         const bool chain_plan = chain && plan_has_room();
         bool xavg_deferred = false;
+        // the row sums of X the DUAL phase starts from: left by the last matrix-core SDDMM (this call's previous iteration, or the chunk
+        // this one continues), otherwise taken by k_dual_rows
+        bool rs_ok = chain && rs_last && rs_enabled && rsfx.p != nullptr;
+        rs_last = false;
         // drawing the next sketch in extra workgroups of the SDDMM launch paid off with 8-wave SDDMM workgroups (+3.7 %); with
         // 16-wave ones (two per CU, every wave slot taken) it costs 1.5 %, so it is opt-in
         const bool fuse_sketch = !kt_exact() && !timing && getenv("MMW_FUSED_SKETCH") != nullptr;
@@ -848,7 +862,9 @@ template <typename T> struct Solver final : mmw_solver {
             MMW_TRY(record(0));
             // ---- DUAL
             MMW_TRY(kt.begin(KT_DUAL));
-            hipLaunchKernelGGL((k_dual_rows<T>), dim3(gr), dim3(BLOCK), 0, st, P, xval.p, rsum.p, e_this.p);
+            const long long* rs_it = rs_ok ? rsfx.p : nullptr;
+            if (rs_it) ++n_rs_iters;
+            if (!rs_it) hipLaunchKernelGGL((k_dual_rows<T>), dim3(gr), dim3(BLOCK), 0, st, P, xval.p, rsum.p, e_this.p);
             // Lagged planning inside a chunk (not the first iteration of a run, a replay or after a change of the iterate, which plan exactly): k_dual_h also takes the row sums of the
             // L it walks over anyway -- last iteration's -- and one extra workgroup of k_softmax_b turns them into this iteration's plan
             // (extrapolated bounds, checked by the next plan): k_rowsums + k_plan leave the critical path.
@@ -863,14 +879,17 @@ template <typename T> struct Solver final : mmw_solver {
             // (kernels_loop.h, k_dual_h / k_dual_scal).  Two launches of the dependent chain fewer.
             const bool fused_dual = optimistic && (it > 0 || chain) && fuse_dual;
             if (fused_dual) {
+                ++n_fused_iters;
                 if (yun.n < (size_t)C) MMW_TRY(yun.alloc((size_t)C));
                 hipLaunchKernelGGL((k_dual_h<T>), dim3(gr), dim3(BLOCK), 0, st, P, rsum.p, e_this.p, e_accu.p, eta, max_part.p,
-                                   (const T*)(lagged_it ? lval.p : nullptr), 0.5, eng.row_part.p, (const double*)(scal.p + 4), yun.p, wH.p, sum_part.p);
+                                   (const T*)(lagged_it ? lval.p : nullptr), 0.5, eng.row_part.p, (const double*)(scal.p + 4), yun.p, wH.p, sum_part.p,
+                                   rs_it, (const T*)xval.p);
                 hipLaunchKernelGGL(k_dual_scal, dim3(1), dim3(DSCAL_THREADS), 0, st, sum_part.p, max_part.p, gr, scal.p,
                                    dual_gap, eng.viol_d.p);
             } else {
                 hipLaunchKernelGGL((k_dual_h<T>), dim3(gr), dim3(BLOCK), 0, st, P, rsum.p, e_this.p, e_accu.p, eta, max_part.p,
-                                   (const T*)(lagged_it ? lval.p : nullptr), 0.5, eng.row_part.p);
+                                   (const T*)(lagged_it ? lval.p : nullptr), 0.5, eng.row_part.p, (const double*)nullptr, (T*)nullptr, (T*)nullptr,
+                                   (double*)nullptr, rs_it, (const T*)xval.p);
                 hipLaunchKernelGGL((k_softmax_a<T>), dim3(gc), dim3(BLOCK), 0, st, P, e_accu.p, Y.p, max_part.p, gr, sum_part.p);
                 hipLaunchKernelGGL((k_softmax_b<T>), dim3(gc + (lagged_it ? 1 : 0)), dim3(BLOCK), 0, st, C, Y.p, yavg.p, acc, sum_part.p, gc, scal.p,
                                    K + (int)H.E_asso(), d_invn.p, wH.p, pa, max_part.p, gr);
@@ -895,12 +914,14 @@ template <typename T> struct Solver final : mmw_solver {
             // the blocked copy of L feeds the fp32 LDS kernel only: while the matrix-core kernel runs the products it is left stale
             const bool mf_it = eng.mfma_now() && eng.method == MMW_EXPM_LANCZOS;
             if (mf_it) lblk_stale = true;
+            const bool rs_zeroed = rs_enabled && rsfx.p != nullptr && sddmm_mfma;  // the coming SDDMM may add its row sums to zeroed totals
             const PlanArgs pl_loss = fused_dual ? pa : PlanArgs{};  // the fused pass has no softmax pass B to lend the planning a workgroup
             hipLaunchKernelGGL((k_loss<T>), dim3(gl + skl.nblocks + (pl_loss.plan ? 1 : 0)), dim3(BLOCK), skl.nblocks && lz_m ? (size_t)WAVES_PER_BLOCK * Dpad * sizeof(double) : 0,
                                st, P, d_lrow.p, fused_dual ? yun.p : Y.p, wH.p, scal.p, lval.p, eta,
                                (const int*)(eng.use_blk && !mf_it ? b_bpos.p : nullptr), lval_blk.p,
                                (const T*)(xavg_deferred ? xval.p : nullptr), xavg_deferred ? xavg.p : (T*)nullptr, skl, Dpad,
-                               (const int*)(eng.use_mfma ? b_fpos.p : nullptr), afrag.p, fused_dual ? Y.p : (T*)nullptr, yavg.p, acc, pl_loss);
+                               (const int*)(eng.use_mfma ? b_fpos.p : nullptr), afrag.p, fused_dual ? Y.p : (T*)nullptr, yavg.p, acc, pl_loss,
+                               rs_zeroed ? rsfx.p : (long long*)nullptr);
             xavg_deferred = false;
             MMW_TRY(kt.end());
             MMW_TRY(record(2));
@@ -942,22 +963,26 @@ template <typename T> struct Solver final : mmw_solver {
             if (eng.method != MMW_EXPM_LANCZOS)
                 hipLaunchKernelGGL((k_rownorm2<T>), dim3(gr), dim3(BLOCK), 0, st, K, Dpad, Xh.p, drow.p, tr_part.p);
             bool sd_done = false;
+            rs_ok = false;
             if constexpr (sizeof(T) == 4) {
                 if (sd_mf) {
                     SdMfmaDev SM;
                     SM.tbase = b_tbase.p; SM.tptr = b_tptr.p; SM.trc = b_trc.p; SM.tepos = b_tepos.p;
                     const dim3 grid((HB.nbm() + 7) / 8 * 8, (HB.m_ntile_max + SDM_GT - 1) / SDM_GT);
+                    SM.tmask = b_tmask.p;
+                    long long* rs_out = rs_zeroed ? rsfx.p : nullptr;  // this iteration's LOSS pass zeroed the totals
                     static bool attr1 = false, attr2 = false;
                     if (HB.mfma_mt == 2) {
                         if (!attr2) { MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sddmm_mfma<2>), hipFuncAttributeMaxDynamicSharedMemorySize, sdm_lds_bytes<2>())); attr2 = true; }
                         hipLaunchKernelGGL((k_sddmm_mfma<2>), grid, dim3(512), sdm_lds_bytes<2>(), st, eng.mf, SM, K, Dpad,
-                                           reinterpret_cast<const char*>(xh_planes.p), drow.p, tr_part.p, gr, d_diag.p, xval.p);
+                                           reinterpret_cast<const char*>(xh_planes.p), drow.p, tr_part.p, gr, d_diag.p, xval.p, rs_out);
                     } else {
                         if (!attr1) { MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sddmm_mfma<1>), hipFuncAttributeMaxDynamicSharedMemorySize, sdm_lds_bytes<1>())); attr1 = true; }
                         hipLaunchKernelGGL((k_sddmm_mfma<1>), grid, dim3(256), sdm_lds_bytes<1>(), st, eng.mf, SM, K, Dpad,
-                                           reinterpret_cast<const char*>(xh_planes.p), drow.p, tr_part.p, gr, d_diag.p, xval.p);
+                                           reinterpret_cast<const char*>(xh_planes.p), drow.p, tr_part.p, gr, d_diag.p, xval.p, rs_out);
                     }
                     sd_done = true;
+                    rs_ok = rs_out != nullptr;
                 }
             }
             if (!sd_done && eng.use_blk) MMW_TRY(ensure_sd());
@@ -1025,6 +1050,7 @@ template <typename T> struct Solver final : mmw_solver {
         // until settle() finds a violation or something touches the iterate.  A handle that has had to replay a chunk keeps restarting
         // its chunks exactly (measured on er-1pct, whose order rises during the run: 5 100 it/s so, 4 500 chained)
         chain_ok = optimistic && n > 1 && replays == 0 && !getenv("MMW_NO_CHUNK_CHAIN");
+        rs_last = rs_ok;
         return MMW_OK;
     }
     int sync() override {
@@ -1106,6 +1132,11 @@ template <typename T> struct Solver final : mmw_solver {
                 if (n != 2) return fail(MMW_ERR_ARG, "spmm kind has 2 entries");
                 out[0] = !eng.use_blk ? 0.0 : (eng.use_mfma ? 3.0 : (eng.blk.half_tile ? 2.0 : 1.0));
                 out[1] = eng.use_mfma && eng.last_mfma_ok ? 1.0 : 0.0;
+                return MMW_OK;
+            }
+            case MMW_F_DUAL_INFO: {
+                if (n != 2) return fail(MMW_ERR_ARG, "dual info has 2 entries");
+                out[0] = (double)n_rs_iters; out[1] = (double)n_fused_iters;
                 return MMW_OK;
             }
             case MMW_F_FACTOR: return extras.read_factor(out, n);

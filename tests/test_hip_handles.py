@@ -287,3 +287,31 @@ def test_chained_chunks_give_the_result_of_chunks_that_restart_exactly(dtype, to
     ref, _ = run()
     for f, x, y in zip(FIELDS, got, ref):
         assert relerr(x, y) < tol, f
+
+
+def test_row_sums_from_the_matrix_core_sddmm_give_the_separate_pass(monkeypatch):
+    """Inside a call the DUAL phase takes the row sums of the off-diagonal X from slabs the matrix-core SDDMM leaves (one slot per
+    union-tile group, summed from the accumulators) instead of k_dual_rows, and makes the D / F violations itself.  Same
+    numbers as the separate pass to fp32 rounding, in the chunked run and in the run that reads every plan back."""
+    state = journal_graph(16, 0.02, seed=4)
+    Z, nit = 24, 60
+    a = _lib.Solver(Z, state, nit, 0.04, dtype=_lib.F32)
+    assert a.read(_lib.F_SPMM_KIND)[0] == 3.0
+    a.iterate(nit, None, seed=9)
+    got = [a.read(f) for f in FIELDS] + [a.read(_lib.F_E_THIS)]
+    assert a.read(_lib.F_DUAL_INFO)[0] >= nit - 8, "all but the first iteration of a chunk that restarts are expected on the slabs"
+    a.close()
+    monkeypatch.setenv("MMW_SYNC_PLAN", "1")
+    c = _lib.Solver(Z, state, nit, 0.04, dtype=_lib.F32)
+    c.iterate(nit, None, seed=9)
+    assert c.read(_lib.F_DUAL_INFO)[0] == nit - 1
+    for f, x in zip(FIELDS + (_lib.F_E_THIS,), got):
+        assert relerr(x, c.read(f)) < 2e-5, f
+    c.close()
+    monkeypatch.setenv("MMW_NO_SDDMM_ROWSUMS", "1")
+    b = _lib.Solver(Z, state, nit, 0.04, dtype=_lib.F32)
+    b.iterate(nit, None, seed=9)
+    assert b.read(_lib.F_DUAL_INFO)[0] == 0
+    for f, x in zip(FIELDS + (_lib.F_E_THIS,), got):
+        assert relerr(x, b.read(f)) < 2e-5, f
+    b.close()
