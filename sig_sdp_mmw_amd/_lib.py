@@ -231,8 +231,10 @@ class Solver:
                 n = self.K * self.D
             elif which in (F_EXPM_INFO, F_BLOCKING):
                 n = 4
-            elif which in (F_SPMM_KIND, F_DUAL_INFO):
+            elif which == F_SPMM_KIND:
                 n = 2
+            elif which == F_DUAL_INFO:
+                n = 3
             elif which == F_E_MAX:
                 n = 1
             elif which == F_PHASE_US:

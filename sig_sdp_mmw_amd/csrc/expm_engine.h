@@ -133,7 +133,7 @@ inline unsigned long long* g_mf_stamps = nullptr;  // diagnostic runs only: per-
 template <int MODE>
 inline int spmm_mfma_launch(hipStream_t st, const MfmaDev& M, int mt, int Dpad, size_t plane_bytes, const char* planes, const float* in,
                             float* out, double ascale, double shift, double* partial, double* partial_o2, const ExpmPlan* plan, int step, int* viol,
-                            MfEpi epi = MfEpi{}) {
+                            MfEpi epi = MfEpi{}, int* grid_out = nullptr /* workgroups launched (the first-order epilogue's trace slab) */) {
     const int ntiles = Dpad / 32;
     const int grid_x = (M.nb + 7) / 8 * 8;
     static int cus = 0;
@@ -155,6 +155,7 @@ inline int spmm_mfma_launch(hipStream_t st, const MfmaDev& M, int mt, int Dpad, 
         hipLaunchKernelGGL((k_spmm_mfma<MODE, MT, NT, NW, MS, KC, NB>), dim3(grid_x, (ntiles + gtw - 1) / gtw), dim3(NW * 64),         \
                            lds_bytes, st, M, Dpad, plane_bytes, planes, in, out, ascale, shift, partial, partial_o2,                   \
                            plan, step, viol, g_mf_stamps, epi);                                                                        \
+        if (grid_out) *grid_out = grid_x * ((ntiles + gtw - 1) / gtw);                                                                 \
     } while (0)
     int gt = 12;  // column tiles per workgroup: 12, 8 or 4
     static const int gt_env = getenv("MMW_MF_GT") ? atoi(getenv("MMW_MF_GT")) : 0;
@@ -425,6 +426,29 @@ template <typename T> struct ExpmEngine {
         MMW_HIP(hipMemsetAsync(viol_d.p, 0, sizeof(int), st));
         return MMW_OK;
     }
+
+    // The whole exponential in ONE product (fp32 handles on the matrix cores; the loop's optimistic chunks while one Lanczos step is
+    // accepted with room): y = u + (ascale A - mu I) u, certified afterwards by first_order_bound from the column sums this launch
+    // leaves in partial_o2 (k_sddmm_mfma's verification workgroup).  No scalar launch, no combination: y leaves the product's
+    // epilogue as the SDDMM's planes (and as fp32 in `out` when given), its row norms as fixed-point totals in `dfx` (zero at launch)
+    // and the trace as one share per workgroup in `tr_part` (*ntr entries).  A uniform factor e^mu is dropped: X = y y^T / tr.
+    int apply_first(T* out, double ascale, int m_launch, bool plan_made, unsigned short* y_planes, long long* dfx, double* tr_part, int* ntr) {
+        if constexpr (std::is_same<T, float>::value) {
+            if (!plan_made) MMW_TRY(make_plan(ascale, m_launch));
+            MMW_TRY(make_planes(0));
+            MfEpi E;
+            E.y_planes = y_planes; E.dfx = dfx; E.tr_part = tr_part;
+            MMW_TRY(kbegin(KT_SPMM));
+            MMW_TRY((spmm_mfma_launch<SPMM_FIRST>(st, mf, mf_mt, lay.Dpad, bs * sizeof(unsigned short), reinterpret_cast<const char*>(planes_of(0)), U.p, out, ascale,
+                                                  0.0, partial.p, partial_o2.p, plan_d.p, 1, viol_d.p, E, ntr)));
+            MMW_TRY(kend());
+            planes_ready[0] = false;
+            start_colsq_ready = false;
+            return MMW_OK;
+        }
+        return fail(MMW_ERR_STATE, "the first-order product runs on fp32 matrix-core handles only");
+    }
+    int first_grid_max() const { return (mf.nb + 7) / 8 * 8 * (lay.Dpad / 32); }  // upper bound of apply_first's *ntr
 
     // out = exp(ascale*A) * start_block().  `out` must not alias the engine's blocks.
     // plan_made: the caller's own kernels already left this application's (lagged) plan in plan_d

@@ -38,7 +38,12 @@ struct ExpmPlan {      // written by k_plan, read by every expm kernel
     double h_pp, h_pm, h_mu;  // its sums: max_i (d_i + o_i), max_i (o_i - d_i), trace / K
     double g_pp, g_pm, g_mu;  // growth per iteration of those sums (last finite difference)
     unsigned conv[MAX_ORDER + 2];  // conv[j]: float bits of the largest per-column estimate after j steps (valid once step j's scalars ran)
+    unsigned first_est;  // float bits of the largest per-column error bound of the first-order form y = u + (A - mu I) u (first_order_bound)
 };
+// exp(A')u = u + A'u + R with ||R|| <= sum_{k>=2} rho^(k-1) ||A'u|| / k! <= ||A'u|| (rho/2) e^rho for any rho >= ||A'||_2 (the 1-norm bound of
+// the symmetric A' is one), and ||exp(A')u|| >= e^-rho ||u||: the relative error of the first-order form is at most q (rho/2) e^(2 rho),
+// q = ||A'u|| / ||u|| measured on the column.
+__device__ __forceinline__ double first_order_bound(double q, double rho) { return q * 0.5 * rho * exp(2.0 * rho); }
 // Steps that run, given the estimates of the steps <= upto that have completed.  The a-priori order is a bound from the
 // 1-norm; the estimate (k_lz_scalars) uses what the recurrence has seen of the operator and typically stops 1-2 steps
 // earlier.  Every kernel of a later step evaluates this and returns at once.
@@ -55,7 +60,7 @@ __device__ __forceinline__ int plan_steps(const ExpmPlan* p, int upto) {
     return m;
 }
 
-enum { SPMM_PLAIN = 0, SPMM_LANCZOS = 1, SPMM_TAYLOR = 2, SPMM_AXPBY = 3 };
+enum { SPMM_PLAIN = 0, SPMM_LANCZOS = 1, SPMM_TAYLOR = 2, SPMM_AXPBY = 3, SPMM_FIRST = 4 /* kernels_mfma.h only */ };
 
 // Out = ascale * A * U (+ mode-specific fused epilogue).  One wavefront per matrix row, grid-stride.
 //   SPMM_LANCZOS: also partial[block][col] = sum_rows U[row,col] * Out[row,col]   (alpha numerators)
@@ -1139,6 +1144,11 @@ __global__ __launch_bounds__(1024) void k_lz_scalars(int nbA, const double* __re
     if (j == 1) phi2 = texp_order1(Dpad, c, inv_nsub, S, scale);
     else phi2 = texp_core<NMAX>(Dpad, c, j, inv_nsub, S, scale, true);
     const double n2 = si * si * to;
+    if (j == 1) {  // what the first-order form would have cost on this column (the host decides from it whether the next chunk takes that form)
+        float ff = (float)first_order_bound(sqrt(n2 > 0.0 ? n2 : 0.0), plan->rho);
+        if (!(ff >= 0.0f)) ff = __uint_as_float(0x7f800000u);
+        atomicMax(&plan->first_est, __float_as_uint(ff));
+    }
     double bj2 = n2 - alpha * alpha - bprev * bprev;
     const double floor2 = 4.0 * eps * n2;  // cancellation floor of the difference (the products were rounded to T)
     if (!(bj2 > floor2)) bj2 = floor2;
@@ -1405,6 +1415,7 @@ __device__ __forceinline__ void plan_body(int K, int method, int max_order, doub
         // the a-posteriori stop needs the shifted recurrence of the half-tile SpMM, a single substep and a geometric tail
         p.apost = apost && method == 0 && nsub == 1 && !p.overflow && r < 0.5;
         for (int i = 0; i < MAX_ORDER + 2; ++i) p.conv[i] = 0u;  // identity of the maximum; a step's entry is read only after its k_lz_scalars ran
+        p.first_est = 0u;
         if (m_launch > 0 && (nsub > 1 || m > m_launch || p.overflow)) {
             // more than the host launched: with the estimate on, the combination decides whether the launched steps were
             // enough after all; without it the batch is replayed

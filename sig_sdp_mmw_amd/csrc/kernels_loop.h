@@ -77,7 +77,15 @@ __global__ __launch_bounds__(BLOCK) void k_dual_h(PatternDev<T> P, const T* __re
                                                   double* __restrict__ lpart = nullptr /* [3][grid], as k_rowsums */,
                                                   const double* __restrict__ mref = nullptr, T* __restrict__ Yun = nullptr,
                                                   T* __restrict__ wun = nullptr, double* __restrict__ sum_part = nullptr /* [4][grid] */,
-                                                  const long long* __restrict__ rsfx = nullptr /* [K] */, const T* __restrict__ xval = nullptr) {
+                                                  const long long* __restrict__ rsfx = nullptr /* [K] */, const T* __restrict__ xval = nullptr,
+                                                  FirstVerify V = FirstVerify{}) {
+    // V.plan: the last V.nwg workgroups of the launch do not take rows; they certify the first-order exponential of the iteration
+    // before (kernels_mfma.h, first_verify) -- short independent work under a latency-bound pass.
+    const int G = (int)gridDim.x - (V.plan ? V.nwg : 0);  // workgroups of the pass itself: the slabs' stride
+    if ((int)blockIdx.x >= G) {
+        first_verify(V, (int)blockIdx.x - G);
+        return;
+    }
     // With `rsfx` the row sums of X come from the matrix-core SDDMM (k_sddmm_mfma: 2^-40 fixed point) instead of k_dual_rows, and
     // the D / F violations that kernel made are taken here from `xval` (mmw.py:127,131).
     // With `mref` (the maximum of e_accu one iteration ago, left in scal[4]) the pass also does softmax pass A's work with that
@@ -91,36 +99,63 @@ __global__ __launch_bounds__(BLOCK) void k_dual_h(PatternDev<T> P, const T* __re
     double sD = 0.0, sF = 0.0, sH = 0.0, sW = 0.0;
     double sd = 0.0, pp = -1e300, pm = -1e300;  // sums of L for the (lagged) plan of the exponential, when lval is given
     const int baseH = K + P.E_asso;
-    for (int row = blockIdx.x * WAVES_PER_BLOCK + wib; row < K; row += gridDim.x * WAVES_PER_BLOCK) {
+    // One row per HALF wavefront (32 lanes): the pass holds 90 registers -- five wavefronts per SIMD, 1 280 workgroups in flight -- and
+    // with one row per wavefront its ~K/4 workgroups ran in two rounds of this latency-bound work; K/8 workgroups' worth runs in one.
+    const int hl = lane & 31, half = lane >> 5;
+    constexpr int UNR = 6;  // 32-lane slices of a row requested together (192 entries: most rows in one go)
+    for (int rbase = (blockIdx.x * WAVES_PER_BLOCK + wib) * 2; rbase < K; rbase += G * WAVES_PER_BLOCK * 2) {
+        const bool valid = rbase + half < K;
+        const int row = valid ? rbase + half : rbase;
         double s = 0.0, la = 0.0, ld = 0.0;
         // the row's own scalars do not depend on the sum: requested up front, they arrive under the entries' loads instead of adding
-        // a memory round trip to lane 0's tail
+        // a memory round trip to the tail of the half's first lane
         const double r_hmax = (double)P.h_max[row], r_ssum = (double)P.S_sum[row], r_invn = (double)P.inv_norm_H[row];
         const double r_eacc = (double)e_accu[baseH + row], r_cH = mref ? (double)P.cH[row] : 0.0;
-        for (int e = P.indptr[row] + lane; e < P.indptr[row + 1]; e += WAVE) {
-            const double w = (double)P.sab[e];
-            const int c = P.col[e];
-            if (w != 0.0) {
-                const double rc = rsfx ? (double)rsfx[c] * (1.0 / SDM_FX) : (double)rsum[c];
-                s += w * rc;
+        // branch-free slices: every slice's entry loads are requested together and then every slice's gather (a loop over slices
+        // made each gather wait for its own entries: two memory round trips per slice)
+        const int e_begin = P.indptr[row], e_end = valid ? P.indptr[row + 1] : e_begin;
+        for (int base = e_begin + hl; base < e_end + hl; base += UNR * 32) {
+            T wq[UNR], vq[UNR];
+            int cq[UNR];
+            bool on[UNR];
+#pragma unroll
+            for (int q = 0; q < UNR; ++q) {
+                const int e = base + q * 32;
+                on[q] = e < e_end;
+                const int ee = on[q] ? e : e_begin;
+                wq[q] = P.sab[ee];
+                cq[q] = P.col[ee];
+                vq[q] = lval ? lval[ee] : T(0);
             }
-            if (lval) {  // the pass reads these rows anyway: |L| row sums and the diagonal, like k_rowsums
-                const double v = lscale * (double)lval[e];
-                if (c == row) ld = v;
-                else la += fabs(v);
+            double rq[UNR];
+#pragma unroll
+            for (int q = 0; q < UNR; ++q) {
+                const bool g = on[q] && wq[q] != T(0);
+                const int cc = g ? cq[q] : row;
+                rq[q] = rsfx ? (double)rsfx[cc] * (1.0 / SDM_FX) : (double)rsum[cc];
+                if (!g) rq[q] = 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < UNR; ++q) {
+                s += (double)wq[q] * rq[q];
+                if (lval && on[q]) {  // the pass reads these rows anyway: |L| row sums and the diagonal, like k_rowsums
+                    const double v = lscale * (double)vq[q];
+                    if (cq[q] == row) ld = v;
+                    else la += fabs(v);
+                }
             }
         }
-        s = wave_sum(s);
+        s = group_sum(s, 32);
         if (lval) {
-            la = wave_sum(la);
-            ld = wave_sum(ld);  // exactly one lane holds the diagonal
-            if (lane == 0) {
+            la = group_sum(la, 32);
+            ld = group_sum(ld, 32);  // exactly one lane of the half holds the diagonal
+            if (hl == 0 && valid) {
                 sd += ld;
                 pp = ld + la > pp ? ld + la : pp;
                 pm = la - ld > pm ? la - ld : pm;
             }
         }
-        if (lane == 0) {
+        if (hl == 0 && valid) {
             const double eh = (s * (double)(Z - 1) / (double)Z - (r_hmax - (1.0 / (double)Z) * r_ssum)) * r_invn;  // mmw.py:134
             e_this[baseH + row] = (T)eh;
             const T a = (T)(r_eacc + (double)(T)eh * eta);
@@ -137,7 +172,7 @@ __global__ __launch_bounds__(BLOCK) void k_dual_h(PatternDev<T> P, const T* __re
         }
     }
     const double invK = 1.0 / (double)K, Zm1 = (double)(Z - 1), denF = 1.0 / ((double)K * Zm1) + 0.5;
-    for (int c = blockIdx.x * BLOCK + threadIdx.x; c < baseH; c += gridDim.x * BLOCK) {
+    for (int c = blockIdx.x * BLOCK + threadIdx.x; c < baseH; c += G * BLOCK) {
         T et;
         if (rsfx) {
             et = c < K ? (T)(((double)xval[P.diag_pos[c]] - 1.0) / (1.0 - invK)) : (T)(((double)xval[P.asso_pos[c - K]] + 1.0 / Zm1) / denF);
@@ -170,8 +205,8 @@ __global__ __launch_bounds__(BLOCK) void k_dual_h(PatternDev<T> P, const T* __re
         double t = shr[q][0];
         for (int w = 1; w < WAVES_PER_BLOCK; ++w) t = is_max ? (shr[q][w] > t ? shr[q][w] : t) : t + shr[q][w];
         if (q == 0) max_part[blockIdx.x] = t;
-        else if (q < 4) { if (lval) lpart[(q - 1) * gridDim.x + blockIdx.x] = t; }
-        else if (mref) sum_part[(q - 4) * gridDim.x + blockIdx.x] = t;
+        else if (q < 4) { if (lval) lpart[(q - 1) * G + blockIdx.x] = t; }
+        else if (mref) sum_part[(q - 4) * G + blockIdx.x] = t;
     }
 }
 
@@ -260,7 +295,14 @@ __global__ __launch_bounds__(BLOCK) void k_softmax_b(int C, T* __restrict__ Y, T
 // replayed on the two-pass kernels).
 constexpr int DSCAL_THREADS = 1024;
 __global__ __launch_bounds__(DSCAL_THREADS) void k_dual_scal(const double* __restrict__ sum_part, const double* __restrict__ max_part, int npart,
-                                                            double* __restrict__ scal /* [5] */, double overflow_gap, int* __restrict__ viol) {
+                                                            double* __restrict__ scal /* [5] */, double overflow_gap, int* __restrict__ viol,
+                                                            FirstVerify V = FirstVerify{}) {
+    // workgroups past the first certify the first-order exponential of the iteration before (kernels_mfma.h, first_verify): independent
+    // work beside a one-workgroup launch
+    if (blockIdx.x > 0) {
+        first_verify(V, (int)blockIdx.x - 1);
+        return;
+    }
     __shared__ double sh[5][DSCAL_THREADS / WAVE];
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, m = -1e300;
     for (int i = threadIdx.x; i < npart; i += DSCAL_THREADS) {
@@ -306,7 +348,8 @@ __global__ __launch_bounds__(BLOCK) void k_loss(PatternDev<T> P, const int* __re
                                                 SketchArgs<T> sk = SketchArgs<T>{}, int Dpad = 0, const int* __restrict__ fpos = nullptr,
                                                 unsigned* __restrict__ afrag = nullptr, T* __restrict__ Ynorm = nullptr,
                                                 T* __restrict__ yavg = nullptr, int accumulate = 0, PlanArgs pa = PlanArgs{},
-                                                long long* __restrict__ rs_zero = nullptr /* [K]: row-sum totals the coming SDDMM adds to */) {
+                                                long long* __restrict__ rs_zero = nullptr /* fixed-point totals the coming product / SDDMM add to */,
+                                                int rs_zero_n = 0) {
     // Ynorm != nullptr: Y and wH hold the unnormalised exponentials of the fused DUAL pass (k_dual_h, mref form) and scal[3]
     // their total; this pass divides where it uses them and writes the normalised Y (and its running sum) on the side.
     if ((int)blockIdx.x < sk.nblocks) {  // leading workgroups draw this iteration's sketch (same shape as k_sketch_rng: same bits)
@@ -331,7 +374,7 @@ __global__ __launch_bounds__(BLOCK) void k_loss(PatternDev<T> P, const int* __re
     const double total = Ynorm ? scal[3] : 1.0, inv_total = 1.0 / total;
     const double gscale = (Zm1 / (double)(2 * Z)) * inv_total;
     if (rs_zero)
-        for (int k = bid * BLOCK + threadIdx.x; k < K; k += nb * BLOCK) rs_zero[k] = 0;
+        for (int k = bid * BLOCK + threadIdx.x; k < rs_zero_n; k += nb * BLOCK) rs_zero[k] = 0;
     if (Ynorm)
         for (int c = bid * BLOCK + threadIdx.x; c < P.C; c += nb * BLOCK) {
             const T y = (T)((double)Y[c] / total);

@@ -59,6 +59,7 @@ __global__ __launch_bounds__(BLOCK) void k_split_planes(size_t n4, const float4*
     }
 }
 
+constexpr double SDM_FX = 1099511627776.0;  // 2^40: fixed-point scale of the row totals added with integer atomics (row sums of X, row norms of y)
 constexpr int MF_KROWS = 16;  // union rows per k-step
 constexpr int MF_UNION_ROWS = 640;  // == MF_UNION (blocking.h)
 constexpr int MF_KPAD = 2;    // a block's k-steps are padded to a multiple of this in the fragment image (zero fragments)
@@ -78,6 +79,13 @@ struct MfEpi {
     const float* X2 = nullptr;
     float c3 = 0.f;
     unsigned short* out_planes = nullptr;
+    // SPMM_FIRST (the whole exponential in this launch, y = u + (ascale A - mu I) u; see first_order_bound): y leaves as the two bf16
+    // halves interleaved per 32 columns that k_sddmm_mfma gathers (y_planes) and, when Out is given, as fp32; ||y_row||^2 is
+    // added to dfx[row] as a 2^-40 fixed-point integer (zero at launch; the column groups of a row arrive in any order) and
+    // every workgroup leaves its share of the trace in tr_part[blockIdx.y * gridDim.x + blockIdx.x] (zero where no workgroup works)
+    unsigned short* y_planes = nullptr;
+    long long* dfx = nullptr;
+    double* tr_part = nullptr;
 };
 // a chunk = KC k-steps: per k-step the B image (2 planes x 16 rows x the group's columns), then the A fragments of all KC steps
 // GT = column tiles per workgroup
@@ -115,7 +123,7 @@ __global__ __launch_bounds__(NW * 64)
 void k_spmm_mfma(MfmaDev M, int Dpad, size_t plane_bytes, const char* __restrict__ Upl, const float* __restrict__ U,
                  float* __restrict__ Out, double ascale_d, double shift_d, double* __restrict__ partial, double* __restrict__ partial_o2,
                  const ExpmPlan* __restrict__ plan, int step, int* __restrict__ viol, unsigned long long* __restrict__ stamps, MfEpi E) {
-    static_assert(MODE == SPMM_PLAIN || MODE == SPMM_LANCZOS || MODE == SPMM_AXPBY, "the matrix-core SpMM has the plain, the Lanczos and the AXPBY epilogue");
+    static_assert(MODE == SPMM_PLAIN || MODE == SPMM_LANCZOS || MODE == SPMM_AXPBY || MODE == SPMM_FIRST, "the matrix-core SpMM has the plain, the Lanczos, the AXPBY and the first-order epilogue");
     static_assert(MF_KPAD % KC == 0, "the fragment image pads a block's k-steps to whole chunks");
     // diagnostic runs only (stamps != nullptr): shader-clock sums per wave {prologue, wait + barrier, DMA issue, products, epilogue, steps}
     unsigned long long tk0 = 0, tk1 = 0, acc_wait = 0, acc_issue = 0, acc_comp = 0, t_pro = 0;
@@ -129,6 +137,8 @@ void k_spmm_mfma(MfmaDev M, int Dpad, size_t plane_bytes, const char* __restrict
             if (step > plan_steps(plan, step - 1)) return;
             shifted = plan->apost != 0 && partial_o2 != nullptr;
             if (shifted) shift_d = plan->mu;
+        } else if (MODE == SPMM_FIRST) {
+            shift_d = plan->mu;
         } else if (step > plan->m) return;
         // launched without a plan readback on a matrix whose norm has outgrown the two-half split: the chunk is replayed on the fp32 kernel
         if (!plan->mfma_ok && viol && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *viol = 1;
@@ -297,6 +307,89 @@ void k_spmm_mfma(MfmaDev M, int Dpad, size_t plane_bytes, const char* __restrict
         if (stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_comp += t - tk1; tk1 = t; }
     }
 
+    if constexpr (MODE == SPMM_FIRST) {
+        // ---- first-order epilogue: y = u + o, o = ascale A u - mu u.  Leaves y (planes, optionally fp32), the column sums of o^2 (the
+        // bound's q), the row sums of y^2 and the workgroup's share of the trace.
+        const int h2 = lane >> 5, cl = lane & 31;
+        const float emu = Out ? (float)exp(shift_d) : 1.f;
+        float* red = reinterpret_cast<float*>(bufs);   // [MS][GT * 32] column sums of o^2
+        float* rowred = red + MS * GT * 32;            // [NWN][32 MT] row sums of y^2
+        static_assert((MS * GT * 32 + NWN * 32 * MT) * 4 <= NB * CHUNK, "the epilogue's reductions fit into the chunk buffers");
+        float rn[MTW][16], d2t[NT];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) rn[m][v] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            if (!tile_on[i]) continue;
+            const int col = col0 + (wn * NT + i) * 32 + cl;
+            float dot2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                int rows[16];
+                float u[16], yy[16];
+#pragma unroll
+                for (int v = 0; v < 16; ++v) rows[v] = orow_l[32 * (wm * MTW + m) + (v & 3) + 8 * (v >> 2) + 4 * h2];
+#pragma unroll
+                for (int v = 0; v < 16; ++v) u[v] = U[(size_t)max(rows[v], 0) * Dpad + col];
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float o = ascale * acc[m][i][v] - shift * u[v];
+                    const float y = u[v] + o;
+                    yy[v] = 0.f;
+                    if (rows[v] >= 0) {
+                        dot2 += o * o;
+                        yy[v] = y * y;
+                        if (Out) Out[(size_t)rows[v] * Dpad + col] = y * emu;  // the copy the API hands out is exp(A) u: it carries the factor
+                    }
+                    // y's bf16 halves, two columns per store: the even lane of a pair writes the hi halves of both columns, the odd lane the lo halves
+                    const unsigned w = split_bf16(y);
+                    const unsigned wp = dpp_u32<DPP_QUAD_XOR1>(w);
+                    if (rows[v] >= 0) {
+                        const unsigned val = (cl & 1) ? ((wp & 0xFFFFu) | (w << 16)) : ((w >> 16) | (wp & 0xFFFF0000u));
+                        unsigned short* g = E.y_planes + (size_t)rows[v] * Dpad * 2 + (size_t)(col >> 5) * 64 + ((cl & 1) ? 32 : 0) + (col & 30);
+                        *reinterpret_cast<unsigned*>(g) = val;
+                    }
+                }
+#pragma unroll
+                for (int v = 0; v < 16; ++v) rn[m][v] += group_sum(yy[v], 32);
+            }
+            float a, b;
+            rows32(dot2, a, b);
+            d2t[i] = a + b;
+        }
+        __syncthreads();  // every wave has left the chunk buffers (the loads, products and stores above did not wait for that)
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+            if (tile_on[i] && h2 == 0) red[(wm * GT + wn * NT + i) * 32 + cl] = d2t[i];
+        if (cl == 0) {
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) rowred[wn * (32 * MT) + 32 * (wm * MTW + m) + (v & 3) + 8 * (v >> 2) + 4 * h2] = rn[m][v];
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < ng * 32; t += THREADS) {
+            float d2 = 0.f;
+#pragma unroll
+            for (int g = 0; g < MS; ++g) d2 += red[g * GT * 32 + t];
+            partial_o2[(size_t)rb * Dpad + col0 + t] = (double)d2;
+        }
+        if (wv == 0) {  // a block has at most 64 rows: one wave adds them to the totals and folds the trace share
+            double s = 0.0;
+            if (lane < nrows) {
+                float f = 0.f;
+#pragma unroll
+                for (int g = 0; g < NWN; ++g) f += rowred[g * (32 * MT) + lane];
+                s = (double)f;
+                atomicAdd(reinterpret_cast<unsigned long long*>(E.dfx) + orow_l[lane], (unsigned long long)__double2ll_rn(s * SDM_FX));
+            }
+            s = wave_sum(s);
+            if (lane == 0) E.tr_part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
+        }
+        return;
+    }
     // ---- epilogue on the accumulator layout: lane = column (lane & 31), register v = row (v & 3) + 8 (v >> 2) + 4 (lane >> 5).
     // Rows past the block's last are computed on row 0's address and dropped at the store: no branch around a load, so a tile's
     // 16 loads of u are in flight together.
@@ -408,18 +501,76 @@ struct SdMfmaDev {
     const int* tepos;             // CSR position
     const unsigned short* tmask;  // [tiles][64] accumulator mask of the pattern's entries (blocking.h, m_tmask)
 };
-constexpr double SDM_FX = 1099511627776.0;  // 2^40: fixed-point scale of the row sums k_sddmm_mfma hands to the DUAL phase
 constexpr int SDM_GT = 4;   // union tiles per workgroup
 constexpr int SDM_KC = 2;   // k-steps per chunk (a 128-byte line per row: 64 bytes of hi halves, 64 of lo halves)
 template <int MT> constexpr int sdm_rows() { return 32 * MT + 32 * SDM_GT; }
 template <int MT> constexpr int sdm_chunk_bytes() { return 2 * sdm_rows<MT>() * 32 * SDM_KC; }
 template <int MT> constexpr int sdm_lds_bytes() { return sdm_rows<MT>() * 4 + 2 * sdm_chunk_bytes<MT>(); }
 
+// The first-order exponential (SPMM_FIRST) is certified after the fact, off the critical path: a few spare workgroups of the next
+// iteration's k_dual_h launch (or k_first_verify at the end of a chunk) fold the column sums of o^2 (the product's slabs) and of u^2
+// (the sketch's slabs) into the largest per-column bound, leave it where the Lanczos steps leave theirs (conv[1], m_eff = 1: the
+// host's chunk logic reads the same fields) and raise the replay flag when the bound misses the tolerance or the plan does not allow
+// a single substep.  The next plan (the LOSS pass that follows) resets the fields only afterwards.
+constexpr int FV_COLS = 8;  // columns per verification workgroup (64 bytes of a slab row per thread)
+struct FirstVerify {
+    ExpmPlan* plan = nullptr;  // nullptr: no verification rides in this launch
+    int* viol = nullptr;
+    const double* o2 = nullptr;
+    const double* u2 = nullptr;
+    int n_o2 = 0, n_u2 = 0, Dpad = 0;
+    int nwg = 0;               // verification workgroups: Dpad / FV_COLS
+};
+// workgroup `wg` (256 or 1024 threads) takes the columns [FV_COLS wg, FV_COLS (wg + 1)): one slab row per thread and round, fixed-order sums
+__device__ inline void first_verify(const FirstVerify& V, int wg) {
+    __shared__ double shv[2 * FV_COLS][16];
+    const int BLOCK_V = (int)blockDim.x, NWV = BLOCK_V >> 6;  // 256 or 1024 threads
+    const int c0 = wg * FV_COLS;
+    double acc[2 * FV_COLS];
+#pragma unroll
+    for (int q = 0; q < 2 * FV_COLS; ++q) acc[q] = 0.0;
+    for (int b = threadIdx.x; b < V.n_o2; b += BLOCK_V)
+#pragma unroll
+        for (int q = 0; q < FV_COLS; ++q) acc[q] += V.o2[(size_t)b * V.Dpad + c0 + q];
+    for (int b = threadIdx.x; b < V.n_u2; b += BLOCK_V)
+#pragma unroll
+        for (int q = 0; q < FV_COLS; ++q) acc[FV_COLS + q] += V.u2[(size_t)b * V.Dpad + c0 + q];
+#pragma unroll
+    for (int q = 0; q < 2 * FV_COLS; ++q) {
+        acc[q] = wave_sum(acc[q]);
+        if ((threadIdx.x & 63) == 0) shv[q][threadIdx.x >> 6] = acc[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {  // one column per lane: the double-precision tail of the eight columns runs side by side
+        double e = 0.0;
+        if (threadIdx.x < FV_COLS) {
+            const int q = (int)threadIdx.x;
+            double o2 = 0.0, u2 = 0.0;
+            for (int w = 0; w < NWV; ++w) { o2 += shv[q][w]; u2 += shv[FV_COLS + q][w]; }
+            e = u2 > 0.0 ? first_order_bound(sqrt(o2 / u2), V.plan->rho) : 0.0;
+            if (!(e >= 0.0)) e = 1e300;  // NaN
+        }
+        const double best = wave_max(e);
+        if (threadIdx.x == 0) {
+            float ef = (float)best;
+            if (!(ef >= 0.0f)) ef = __uint_as_float(0x7f800000u);
+            if ((double)ef < best) ef = __uint_as_float(__float_as_uint(ef) + 1u);  // round up
+            atomicMax(&V.plan->conv[1], __float_as_uint(ef));  // maxima: the order of arrival does not matter (the plan zeroed both)
+            atomicMax(&V.plan->first_est, __float_as_uint(ef));
+            if (wg == 0) V.plan->m_eff = 1;
+            if (!(best <= V.plan->tol) || !V.plan->apost || V.plan->nsub != 1 || V.plan->overflow) *V.viol = 1;
+        }
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_first_verify(FirstVerify V) { first_verify(V, (int)blockIdx.x); }
+
 template <int MT>
 __global__ __launch_bounds__(4 * MT * 64)
 void k_sddmm_mfma(MfmaDev M, SdMfmaDev S, int K, int Dpad, const char* __restrict__ Ypl, const float* __restrict__ d,
                   const double* __restrict__ tr_part, int ntr, const int* __restrict__ diag_pos, float* __restrict__ xval,
-                  long long* __restrict__ rsfx = nullptr /* [K], zero at launch */) {
+                  long long* __restrict__ rsfx = nullptr /* [K], zero at launch */, const long long* __restrict__ dfx = nullptr) {
+    // dfx: the row norms as 2^-40 fixed-point totals (SPMM_FIRST) instead of `d`
+    const int by = (int)blockIdx.y;  // union-tile group of this workgroup
     // rsfx: the DUAL phase's first step (mmw.py:133-134, the row sums of the off-diagonal X) leaves with the tiles: every wave sums
     // its tile's pattern entries per row straight from the accumulators, the workgroup's union tiles meet in LDS, and the part of
     // this union-tile group is added to the row's total as a 2^-40 fixed-point integer (|sum| < 2^10 for rows of <= 640 entries
@@ -443,7 +594,7 @@ void k_sddmm_mfma(MfmaDev M, SdMfmaDev S, int K, int Dpad, const char* __restric
     const int* dsc = M.desc + (size_t)rb * 8;
     const int q0 = dsc[0], nrows = dsc[1], nun = dsc[5];
     const int ntile = (nun + 31) >> 5;
-    const int ut0 = blockIdx.y * SDM_GT;  // first union tile of this workgroup
+    const int ut0 = by * SDM_GT;  // first union tile of this workgroup
     if (ut0 >= ntile) return;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -549,10 +700,10 @@ void k_sddmm_mfma(MfmaDev M, SdMfmaDev S, int K, int Dpad, const char* __restric
         __builtin_amdgcn_wave_barrier();
     }
     for (int w = tw0 + lane; w < tw1; w += 64) xval[S.tepos[w]] = (float)((double)tile[S.trc[w]] / tr);
-    if (blockIdx.y == 0)  // the diagonal of the block's rows from the exact row norms
+    if (by == 0)  // the diagonal of the block's rows from the exact row norms
         for (int i = threadIdx.x; i < nrows; i += THREADS) {
             const int row = rows_l[i];
-            xval[diag_pos[row]] = (float)((double)d[row] / tr);
+            xval[diag_pos[row]] = (float)((dfx ? (double)dfx[row] * (1.0 / SDM_FX) : (double)d[row]) / tr);
         }
     if (rsfx)
         for (int i = threadIdx.x; i < nrows; i += THREADS) {

@@ -85,7 +85,12 @@ template <typename T> struct Solver final : mmw_solver {
     DevBuf<unsigned> afrag;          // the matrix as bf16 hi << 16 | lo words in MFMA fragment order
     DevBuf<int> b_tbase, b_tptr, b_tepos;  // matrix-core SDDMM: pattern entries by 32 x 32 output tile
     DevBuf<unsigned short> b_trc, b_tmask, xh_planes;
-    DevBuf<long long> rsfx;  // [K] row sums of the off-diagonal X in 2^-40 fixed point, left by the matrix-core SDDMM (kernels_mfma.h)
+    DevBuf<long long> rsfx;  // [2K] 2^-40 fixed-point totals: [0, K) row sums of the off-diagonal X, left by the matrix-core SDDMM; [K, 2K) row norms of
+                             // y = exp(L/2)R from the first-order product (kernels_mfma.h).  Zeroed by every LOSS pass.
+    DevBuf<double> tr1_part; // trace shares of the first-order product's workgroups (zero where none works)
+    const bool first_enabled = getenv("MMW_NO_FIRST_ORDER") == nullptr;
+    bool first_guess = false;  // the chunk being enqueued takes the first-order exponential (first_order_ok at its start)
+    long long n_first_iters = 0;
     bool rs_last = false;    // the last iteration enqueued left rsfx for the X the next one starts from
     const bool rs_enabled = getenv("MMW_NO_SDDMM_ROWSUMS") == nullptr;
     long long n_rs_iters = 0, n_fused_iters = 0;  // MMW_F_DUAL_INFO
@@ -389,7 +394,7 @@ template <typename T> struct Solver final : mmw_solver {
                 MMW_TRY(b_tbase.upload(HB.m_tbase, st)); MMW_TRY(b_tptr.upload(HB.m_tptr, st)); MMW_TRY(b_trc.upload(HB.m_trc, st));
                 MMW_TRY(b_tepos.upload(HB.m_tepos, st));
                 MMW_TRY(b_tmask.upload(HB.m_tmask, st));
-                MMW_TRY(rsfx.alloc((size_t)K));
+                MMW_TRY(rsfx.alloc((size_t)2 * K));
                 sddmm_mfma = true;
             }
             if ((size_t)HB.nbm() > (size_t)MAX_PART && HB.nbm() > HB.nb()) {
@@ -766,6 +771,7 @@ template <typename T> struct Solver final : mmw_solver {
             if (chain_ok && iter >= 4) cap = std::max(cap, std::min(32, room_iterations()));
             const int chunk = std::min(left, cap);
             if (plan_seen) m_guess = next_launch_order(chunk);  // before the first readback of a run: the default set by reset()
+            first_guess = plan_seen && m_guess == 1 && first_order_ok(chunk);
             MMW_TRY(copy_state(true));
             pend_iter0 = iter; pend_n = chunk; pend_seed = seed; pend_events0 = events.size();
             MMW_TRY(iterate_impl(chunk, nullptr, seed, chunk > 1));
@@ -780,6 +786,17 @@ template <typename T> struct Solver final : mmw_solver {
     // `ahead`: iterations the launch order has to hold for (the coming chunk).  The estimate after m steps grows like ||L||^(2m) and
     // ||L|| like the iteration count: no spare step only if the estimate, grown over the chunk, still meets the tolerance with a
     // factor 2 (and never without the factor 8 at the moment of the readback).
+    // The coming chunk of `ahead` iterations may take the exponential as ONE product, y = u + (L/2 - mu I) u (ExpmEngine::apply_first):
+    // the last plan read back holds the bound that form would have met (first_est, from k_lz_scalars or from the form's own check); it
+    // grows like rho * q ~ t^2, and the same margins as for dropping the spare Lanczos step apply.
+    bool first_order_ok(int ahead) const {
+        const ExpmPlan& p = eng.last;
+        if (!first_enabled || sizeof(T) != 4 || !p.apost || p.m_eff != 1 || p.first_est == 0u) return false;
+        union { unsigned u; float f; } e;
+        e.u = p.first_est;
+        const double grow = std::pow((double)(iter + ahead + 1) / (double)std::max(iter, 1), 2.0);
+        return (double)e.f <= p.tol / 8.0 && (double)e.f * grow <= p.tol / 2.0;
+    }
     int next_launch_order(int ahead = 0) const {
         const ExpmPlan& p = eng.last;
         if (p.m_eff <= 0) return std::min(eng.max_order, p.m + 1);
@@ -852,6 +869,7 @@ template <typename T> struct Solver final : mmw_solver {
         // the row sums of X the DUAL phase starts from: left by the last matrix-core SDDMM (this call's previous iteration, or the chunk
         // this one continues), otherwise taken by k_dual_rows
         bool rs_ok = chain && rs_last && rs_enabled && rsfx.p != nullptr;
+        FirstVerify fv_pending;  // the first-order exponential of the previous iteration of this call still waits for its check
         rs_last = false;
         // drawing the next sketch in extra workgroups of the SDDMM launch paid off with 8-wave SDDMM workgroups (+3.7 %); with
         // 16-wave ones (two per CU, every wave slot taken) it costs 1.5 %, so it is opt-in
@@ -863,6 +881,8 @@ template <typename T> struct Solver final : mmw_solver {
             // ---- DUAL
             MMW_TRY(kt.begin(KT_DUAL));
             const long long* rs_it = rs_ok ? rsfx.p : nullptr;
+            const FirstVerify fv = fv_pending;
+            fv_pending = FirstVerify{};
             if (rs_it) ++n_rs_iters;
             if (!rs_it) hipLaunchKernelGGL((k_dual_rows<T>), dim3(gr), dim3(BLOCK), 0, st, P, xval.p, rsum.p, e_this.p);
             // Lagged planning inside a chunk (not the first iteration of a run, a replay or after a change of the iterate, which plan exactly): k_dual_h also takes the row sums of the
@@ -884,12 +904,12 @@ template <typename T> struct Solver final : mmw_solver {
                 hipLaunchKernelGGL((k_dual_h<T>), dim3(gr), dim3(BLOCK), 0, st, P, rsum.p, e_this.p, e_accu.p, eta, max_part.p,
                                    (const T*)(lagged_it ? lval.p : nullptr), 0.5, eng.row_part.p, (const double*)(scal.p + 4), yun.p, wH.p, sum_part.p,
                                    rs_it, (const T*)xval.p);
-                hipLaunchKernelGGL(k_dual_scal, dim3(1), dim3(DSCAL_THREADS), 0, st, sum_part.p, max_part.p, gr, scal.p,
-                                   dual_gap, eng.viol_d.p);
+                hipLaunchKernelGGL(k_dual_scal, dim3(1 + fv.nwg), dim3(DSCAL_THREADS), 0, st, sum_part.p, max_part.p, gr, scal.p,
+                                   dual_gap, eng.viol_d.p, fv);
             } else {
-                hipLaunchKernelGGL((k_dual_h<T>), dim3(gr), dim3(BLOCK), 0, st, P, rsum.p, e_this.p, e_accu.p, eta, max_part.p,
+                hipLaunchKernelGGL((k_dual_h<T>), dim3(gr + fv.nwg), dim3(BLOCK), 0, st, P, rsum.p, e_this.p, e_accu.p, eta, max_part.p,
                                    (const T*)(lagged_it ? lval.p : nullptr), 0.5, eng.row_part.p, (const double*)nullptr, (T*)nullptr, (T*)nullptr,
-                                   (double*)nullptr, rs_it, (const T*)xval.p);
+                                   (double*)nullptr, rs_it, (const T*)xval.p, fv);
                 hipLaunchKernelGGL((k_softmax_a<T>), dim3(gc), dim3(BLOCK), 0, st, P, e_accu.p, Y.p, max_part.p, gr, sum_part.p);
                 hipLaunchKernelGGL((k_softmax_b<T>), dim3(gc + (lagged_it ? 1 : 0)), dim3(BLOCK), 0, st, C, Y.p, yavg.p, acc, sum_part.p, gc, scal.p,
                                    K + (int)H.E_asso(), d_invn.p, wH.p, pa, max_part.p, gr);
@@ -915,13 +935,16 @@ template <typename T> struct Solver final : mmw_solver {
             const bool mf_it = eng.mfma_now() && eng.method == MMW_EXPM_LANCZOS;
             if (mf_it) lblk_stale = true;
             const bool rs_zeroed = rs_enabled && rsfx.p != nullptr && sddmm_mfma;  // the coming SDDMM may add its row sums to zeroed totals
+            // the exponential of this iteration as one first-order product (decided per chunk, first_order_ok)
+            const bool first_it = optimistic && first_guess && m_launch == 1 && !randv && rs_zeroed && sizeof(T) == 4 && eng.mfma_now() &&
+                                  eng.method == MMW_EXPM_LANCZOS && eng.use_blk && (Dpad % 32) == 0;
             const PlanArgs pl_loss = fused_dual ? pa : PlanArgs{};  // the fused pass has no softmax pass B to lend the planning a workgroup
             hipLaunchKernelGGL((k_loss<T>), dim3(gl + skl.nblocks + (pl_loss.plan ? 1 : 0)), dim3(BLOCK), skl.nblocks && lz_m ? (size_t)WAVES_PER_BLOCK * Dpad * sizeof(double) : 0,
                                st, P, d_lrow.p, fused_dual ? yun.p : Y.p, wH.p, scal.p, lval.p, eta,
                                (const int*)(eng.use_blk && !mf_it ? b_bpos.p : nullptr), lval_blk.p,
                                (const T*)(xavg_deferred ? xval.p : nullptr), xavg_deferred ? xavg.p : (T*)nullptr, skl, Dpad,
                                (const int*)(eng.use_mfma ? b_fpos.p : nullptr), afrag.p, fused_dual ? Y.p : (T*)nullptr, yavg.p, acc, pl_loss,
-                               rs_zeroed ? rsfx.p : (long long*)nullptr);
+                               rs_zeroed ? rsfx.p : (long long*)nullptr, rs_zeroed ? (first_it ? 2 * K : K) : 0);
             xavg_deferred = false;
             MMW_TRY(kt.end());
             MMW_TRY(record(2));
@@ -958,7 +981,17 @@ template <typename T> struct Solver final : mmw_solver {
             eng.rownorm_d = drow.p;  // the Lanczos combination also emits the row norms and the trace slabs
             eng.rownorm_part = tr_part.p;
             eng.plan_iter = iter;
-            MMW_TRY(eng.apply(Xh.p, 0.5, m_launch, lagged_it));
+            int ntr1 = 0;
+            if (first_it) {
+                const size_t need = (size_t)eng.first_grid_max();
+                if (tr1_part.n < need) {
+                    MMW_TRY(tr1_part.alloc(need));
+                    MMW_HIP(hipMemsetAsync(tr1_part.p, 0, need * sizeof(double), st));
+                }
+                MMW_TRY(eng.apply_first(eng.planes_only ? (T*)nullptr : Xh.p, 0.5, m_launch, lagged_it, xh_planes.p, rsfx.p + K, tr1_part.p, &ntr1));
+                ++n_first_iters;
+            } else
+                MMW_TRY(eng.apply(Xh.p, 0.5, m_launch, lagged_it));
             MMW_TRY(kt.begin(KT_SDDMM));
             if (eng.method != MMW_EXPM_LANCZOS)
                 hipLaunchKernelGGL((k_rownorm2<T>), dim3(gr), dim3(BLOCK), 0, st, K, Dpad, Xh.p, drow.p, tr_part.p);
@@ -968,6 +1001,9 @@ template <typename T> struct Solver final : mmw_solver {
                 if (sd_mf) {
                     SdMfmaDev SM;
                     SM.tbase = b_tbase.p; SM.tptr = b_tptr.p; SM.trc = b_trc.p; SM.tepos = b_tepos.p;
+                    const long long* dfx = first_it ? rsfx.p + K : nullptr;
+                    const double* trp = first_it ? tr1_part.p : tr_part.p;
+                    const int ntr = first_it ? ntr1 : gr;
                     const dim3 grid((HB.nbm() + 7) / 8 * 8, (HB.m_ntile_max + SDM_GT - 1) / SDM_GT);
                     SM.tmask = b_tmask.p;
                     long long* rs_out = rs_zeroed ? rsfx.p : nullptr;  // this iteration's LOSS pass zeroed the totals
@@ -975,13 +1011,17 @@ template <typename T> struct Solver final : mmw_solver {
                     if (HB.mfma_mt == 2) {
                         if (!attr2) { MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sddmm_mfma<2>), hipFuncAttributeMaxDynamicSharedMemorySize, sdm_lds_bytes<2>())); attr2 = true; }
                         hipLaunchKernelGGL((k_sddmm_mfma<2>), grid, dim3(512), sdm_lds_bytes<2>(), st, eng.mf, SM, K, Dpad,
-                                           reinterpret_cast<const char*>(xh_planes.p), drow.p, tr_part.p, gr, d_diag.p, xval.p, rs_out);
+                                           reinterpret_cast<const char*>(xh_planes.p), drow.p, trp, ntr, d_diag.p, xval.p, rs_out, dfx);
                     } else {
                         if (!attr1) { MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sddmm_mfma<1>), hipFuncAttributeMaxDynamicSharedMemorySize, sdm_lds_bytes<1>())); attr1 = true; }
                         hipLaunchKernelGGL((k_sddmm_mfma<1>), grid, dim3(256), sdm_lds_bytes<1>(), st, eng.mf, SM, K, Dpad,
-                                           reinterpret_cast<const char*>(xh_planes.p), drow.p, tr_part.p, gr, d_diag.p, xval.p, rs_out);
+                                           reinterpret_cast<const char*>(xh_planes.p), drow.p, trp, ntr, d_diag.p, xval.p, rs_out, dfx);
                     }
                     sd_done = true;
+                    if (first_it) {  // certified by spare workgroups of the next iteration's k_dual_h, or by a launch of its own after the chunk's last
+                        fv_pending.plan = eng.plan_d.p; fv_pending.viol = eng.viol_d.p; fv_pending.o2 = eng.partial_o2.p; fv_pending.n_o2 = eng.mf.nb;
+                        fv_pending.u2 = eng.partial_sq.p; fv_pending.n_u2 = eng.npart_start; fv_pending.Dpad = Dpad; fv_pending.nwg = Dpad / FV_COLS;
+                    }
                     rs_ok = rs_out != nullptr;
                 }
             }
@@ -1040,6 +1080,10 @@ template <typename T> struct Solver final : mmw_solver {
             MMW_HIP(hipGetLastError());
             MMW_TRY(record(3));
             ++iter;
+        }
+        if (fv_pending.plan) {  // the chunk's last first-order exponential
+            hipLaunchKernelGGL(k_first_verify, dim3(fv_pending.nwg), dim3(BLOCK), 0, st, fv_pending);
+            MMW_HIP(hipGetLastError());
         }
         if (optimistic && n > 1 && lag_chunk && eng.method == MMW_EXPM_LANCZOS) {
             // the chunk's last plan was extrapolated and no later plan of the chunk sees its matrix: check it here
@@ -1135,8 +1179,8 @@ template <typename T> struct Solver final : mmw_solver {
                 return MMW_OK;
             }
             case MMW_F_DUAL_INFO: {
-                if (n != 2) return fail(MMW_ERR_ARG, "dual info has 2 entries");
-                out[0] = (double)n_rs_iters; out[1] = (double)n_fused_iters;
+                if (n != 3) return fail(MMW_ERR_ARG, "dual info has 3 entries");
+                out[0] = (double)n_rs_iters; out[1] = (double)n_fused_iters; out[2] = (double)n_first_iters;
                 return MMW_OK;
             }
             case MMW_F_FACTOR: return extras.read_factor(out, n);

@@ -214,3 +214,26 @@ def test_full_size_exponential_meets_the_tolerance_when_stopped_early(eta, nit):
     assert err < 2e-6, (err, info)           # tolerance 1e-6 + fp32 rounding of a K x D block (~4e-8 per entry)
     assert info[1] >= 1
     s.close()
+
+
+def test_full_size_first_order_exponential_meets_the_tolerance():
+    """journal N=10 003, D=372, fp32: the last iteration of a chunked run takes exp(L/2)R as one first-order product (it leaves the fp32
+    copy with the factor e^mu the product itself drops); against scipy's expm_multiply on the same L and sketch, first 24 columns."""
+    from scipy.sparse.linalg import expm_multiply
+    state, Z = journal_graph(28, 0.0319, 0), 186
+    nit = 120
+    s = _lib.Solver(Z, state, nit + 1, 0.04, dtype=_lib.F32)
+    s.set_expm(_lib.EXPM_LANCZOS, 12, 1e-6)
+    s.iterate(nit, None, seed=11)
+    s.sync()
+    first = s.read(_lib.F_DUAL_INFO)[2]
+    assert first >= nit // 2 and s.read(_lib.F_BLOCKING)[3] == 0, (first, s.read(_lib.F_BLOCKING))
+    ip, ix = s.read_i32(_lib.I_L_INDPTR), s.read_i32(_lib.I_L_INDICES)
+    K = s.K
+    L = scipy.sparse.csr_matrix((s.read(_lib.F_LVAL), ix, ip), shape=(K, K))
+    R = s.read(_lib.F_SKETCH)[:, :24]
+    got = s.read(_lib.F_XHALF)[:, :24]
+    ref = expm_multiply(0.5 * L, R)
+    err = relerr(got, ref)
+    assert err < 2e-6, err
+    s.close()

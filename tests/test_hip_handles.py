@@ -315,3 +315,51 @@ def test_row_sums_from_the_matrix_core_sddmm_give_the_separate_pass(monkeypatch)
     for f, x in zip(FIELDS + (_lib.F_E_THIS,), got):
         assert relerr(x, b.read(f)) < 2e-5, f
     b.close()
+
+
+def test_first_order_exponential_gives_the_lanczos_run(monkeypatch):
+    """While one Lanczos step is accepted with room, a chunk takes exp(L/2)R as ONE product, y = u + (L/2 - mu I)u, certified after the
+    fact by ||A'u|| rho/2 e^(2 rho) per column (no scalar launch, no combination).  Both forms meet the same tolerance: the runs agree to
+    it, and the first-order run replays nothing."""
+    state = journal_graph(16, 0.02, seed=4)
+    Z, nit = 24, 60
+    a = _lib.Solver(Z, state, nit, 0.04, dtype=_lib.F32)
+    a.iterate(nit, None, seed=9)
+    got = [a.read(f) for f in FIELDS]
+    info = a.read(_lib.F_DUAL_INFO)
+    assert info[2] >= nit // 3, info  # chunks after the first plan readbacks
+    assert a.read(_lib.F_BLOCKING)[3] == 0
+    a.close()
+    monkeypatch.setenv("MMW_NO_FIRST_ORDER", "1")
+    b = _lib.Solver(Z, state, nit, 0.04, dtype=_lib.F32)
+    b.iterate(nit, None, seed=9)
+    assert b.read(_lib.F_DUAL_INFO)[2] == 0
+    for f, x in zip(FIELDS, got):
+        assert relerr(x, b.read(f)) < 2e-5, f
+    b.close()
+
+
+def test_first_order_exponential_is_replayed_when_its_bound_misses_the_tolerance(monkeypatch):
+    """A tolerance tightened between two calls makes the chunk that was planned on the old one miss its bound: the verification that rides
+    in the SDDMM launch raises the replay flag and the chunk is redone with Lanczos steps -- the result is the synchronous run's."""
+    state = journal_graph(16, 0.02, seed=4)
+    Z, nit = 24, 48
+    a = _lib.Solver(Z, state, nit, 0.04, dtype=_lib.F32)
+    a.iterate(32, None, seed=9)
+    a.sync()
+    first0 = a.read(_lib.F_DUAL_INFO)[2]
+    assert first0 > 0 and a.read(_lib.F_BLOCKING)[3] == 0
+    a.set_expm(_lib.EXPM_LANCZOS, 12, 1e-9)
+    a.iterate(16, None, seed=9)
+    a.sync()
+    assert a.read(_lib.F_BLOCKING)[3] >= 1, "the chunk planned on the old tolerance is expected to be replayed"
+    got = [a.read(f) for f in FIELDS]
+    a.close()
+    monkeypatch.setenv("MMW_SYNC_PLAN", "1")
+    b = _lib.Solver(Z, state, nit, 0.04, dtype=_lib.F32)
+    b.iterate(32, None, seed=9)
+    b.set_expm(_lib.EXPM_LANCZOS, 12, 1e-9)
+    b.iterate(16, None, seed=9)
+    for f, x in zip(FIELDS, got):
+        assert relerr(x, b.read(f)) < 2e-5, f
+    b.close()
