@@ -99,63 +99,36 @@ __global__ __launch_bounds__(BLOCK) void k_dual_h(PatternDev<T> P, const T* __re
     double sD = 0.0, sF = 0.0, sH = 0.0, sW = 0.0;
     double sd = 0.0, pp = -1e300, pm = -1e300;  // sums of L for the (lagged) plan of the exponential, when lval is given
     const int baseH = K + P.E_asso;
-    // One row per HALF wavefront (32 lanes): the pass holds 90 registers -- five wavefronts per SIMD, 1 280 workgroups in flight -- and
-    // with one row per wavefront its ~K/4 workgroups ran in two rounds of this latency-bound work; K/8 workgroups' worth runs in one.
-    const int hl = lane & 31, half = lane >> 5;
-    constexpr int UNR = 6;  // 32-lane slices of a row requested together (192 entries: most rows in one go)
-    for (int rbase = (blockIdx.x * WAVES_PER_BLOCK + wib) * 2; rbase < K; rbase += G * WAVES_PER_BLOCK * 2) {
-        const bool valid = rbase + half < K;
-        const int row = valid ? rbase + half : rbase;
+    for (int row = blockIdx.x * WAVES_PER_BLOCK + wib; row < K; row += G * WAVES_PER_BLOCK) {
         double s = 0.0, la = 0.0, ld = 0.0;
         // the row's own scalars do not depend on the sum: requested up front, they arrive under the entries' loads instead of adding
-        // a memory round trip to the tail of the half's first lane
+        // a memory round trip to lane 0's tail
         const double r_hmax = (double)P.h_max[row], r_ssum = (double)P.S_sum[row], r_invn = (double)P.inv_norm_H[row];
         const double r_eacc = (double)e_accu[baseH + row], r_cH = mref ? (double)P.cH[row] : 0.0;
-        // branch-free slices: every slice's entry loads are requested together and then every slice's gather (a loop over slices
-        // made each gather wait for its own entries: two memory round trips per slice)
-        const int e_begin = P.indptr[row], e_end = valid ? P.indptr[row + 1] : e_begin;
-        for (int base = e_begin + hl; base < e_end + hl; base += UNR * 32) {
-            T wq[UNR], vq[UNR];
-            int cq[UNR];
-            bool on[UNR];
-#pragma unroll
-            for (int q = 0; q < UNR; ++q) {
-                const int e = base + q * 32;
-                on[q] = e < e_end;
-                const int ee = on[q] ? e : e_begin;
-                wq[q] = P.sab[ee];
-                cq[q] = P.col[ee];
-                vq[q] = lval ? lval[ee] : T(0);
+        for (int e = P.indptr[row] + lane; e < P.indptr[row + 1]; e += WAVE) {
+            const double w = (double)P.sab[e];
+            const int c = P.col[e];
+            if (w != 0.0) {
+                const double rc = rsfx ? (double)rsfx[c] * (1.0 / SDM_FX) : (double)rsum[c];
+                s += w * rc;
             }
-            double rq[UNR];
-#pragma unroll
-            for (int q = 0; q < UNR; ++q) {
-                const bool g = on[q] && wq[q] != T(0);
-                const int cc = g ? cq[q] : row;
-                rq[q] = rsfx ? (double)rsfx[cc] * (1.0 / SDM_FX) : (double)rsum[cc];
-                if (!g) rq[q] = 0.0;
-            }
-#pragma unroll
-            for (int q = 0; q < UNR; ++q) {
-                s += (double)wq[q] * rq[q];
-                if (lval && on[q]) {  // the pass reads these rows anyway: |L| row sums and the diagonal, like k_rowsums
-                    const double v = lscale * (double)vq[q];
-                    if (cq[q] == row) ld = v;
-                    else la += fabs(v);
-                }
+            if (lval) {  // the pass reads these rows anyway: |L| row sums and the diagonal, like k_rowsums
+                const double v = lscale * (double)lval[e];
+                if (c == row) ld = v;
+                else la += fabs(v);
             }
         }
-        s = group_sum(s, 32);
+        s = wave_sum(s);
         if (lval) {
-            la = group_sum(la, 32);
-            ld = group_sum(ld, 32);  // exactly one lane of the half holds the diagonal
-            if (hl == 0 && valid) {
+            la = wave_sum(la);
+            ld = wave_sum(ld);  // exactly one lane holds the diagonal
+            if (lane == 0) {
                 sd += ld;
                 pp = ld + la > pp ? ld + la : pp;
                 pm = la - ld > pm ? la - ld : pm;
             }
         }
-        if (hl == 0 && valid) {
+        if (lane == 0) {
             const double eh = (s * (double)(Z - 1) / (double)Z - (r_hmax - (1.0 / (double)Z) * r_ssum)) * r_invn;  // mmw.py:134
             e_this[baseH + row] = (T)eh;
             const T a = (T)(r_eacc + (double)(T)eh * eta);
