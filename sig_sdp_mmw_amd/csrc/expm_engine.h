@@ -146,7 +146,7 @@ inline int spmm_mfma_launch(hipStream_t st, const MfmaDev& M, int mt, int Dpad, 
     do {                                                                                                                               \
         static bool attr_set = false;                                                                                                  \
         constexpr int gtw = (NW / MS) * NT;                                                                                            \
-        constexpr int lds_bytes = mf_lds_bytes<MT, gtw, KC, NB>();                                                                     \
+        constexpr int lds_bytes = mf_lds_bytes<MT, gtw, KC, NB, mf_planes(MODE)>();                                                                     \
         if (!attr_set) {                                                                                                               \
             MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_mfma<MODE, MT, NT, NW, MS, KC, NB>),                     \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));                                       \
@@ -311,6 +311,7 @@ template <typename T> struct ExpmEngine {
     // wrote them (planes_ready)
     unsigned short* planes_of(int idx) { return planes.p + (size_t)idx * 2 * bs; }
     bool planes_ready[MAX_ORDER + 2] = {false};
+    bool planes0_f16 = false;  // the start block's planes hold ONE fp16 plane (the first-order product's operand) instead of bf16 hi / lo
     int reserve_planes() {  // at creation: the planes of the Krylov blocks the matrix-core products read
         if (planes.n < (size_t)ublocks * 2 * bs) MMW_TRY(planes.alloc((size_t)ublocks * 2 * bs));
         for (auto& r : planes_ready) r = false;
@@ -332,7 +333,9 @@ template <typename T> struct ExpmEngine {
     int make_planes(int idx) {
         if constexpr (std::is_same<T, float>::value) {
             MMW_TRY(ensure_planes());
+            if (idx == 0 && planes0_f16) planes_ready[0] = false;  // written for the first-order product: not the two bf16 halves
             if (planes_ready[idx]) return MMW_OK;
+            if (idx == 0) planes0_f16 = false;
             MMW_TRY(kbegin(KT_KRYLOV_VEC));
             hipLaunchKernelGGL(k_split_planes, dim3(grid_elems(bs / 4)), dim3(BLOCK), 0, st, bs / 4, reinterpret_cast<const float4*>(block(idx)),
                                reinterpret_cast<uint2*>(planes_of(idx)), reinterpret_cast<uint2*>(planes_of(idx) + bs));
@@ -435,14 +438,22 @@ template <typename T> struct ExpmEngine {
     int apply_first(T* out, double ascale, int m_launch, bool plan_made, unsigned short* y_planes, long long* dfx, double* tr_part, int* ntr) {
         if constexpr (std::is_same<T, float>::value) {
             if (!plan_made) MMW_TRY(make_plan(ascale, m_launch));
-            MMW_TRY(make_planes(0));
+            MMW_TRY(ensure_planes());
+            if (!(planes_ready[0] && planes0_f16)) {  // the sketch's producer did not leave the fp16 plane
+                MMW_TRY(kbegin(KT_KRYLOV_VEC));
+                hipLaunchKernelGGL(k_plane_f16, dim3(grid_elems(bs / 4)), dim3(BLOCK), 0, st, bs / 4, reinterpret_cast<const float4*>(U.p),
+                                   reinterpret_cast<uint2*>(planes_of(0)));
+                MMW_HIP(hipGetLastError());
+                MMW_TRY(kend());
+            }
             MfEpi E;
             E.y_planes = y_planes; E.dfx = dfx; E.tr_part = tr_part;
             MMW_TRY(kbegin(KT_SPMM));
-            MMW_TRY((spmm_mfma_launch<SPMM_FIRST>(st, mf, mf_mt, lay.Dpad, bs * sizeof(unsigned short), reinterpret_cast<const char*>(planes_of(0)), U.p, out, ascale,
-                                                  0.0, partial.p, partial_o2.p, plan_d.p, 1, viol_d.p, E, ntr)));
+            MMW_TRY((spmm_mfma_launch<SPMM_FIRST>(st, mf, mf_mt, lay.Dpad, bs * sizeof(unsigned short), reinterpret_cast<const char*>(planes_of(0)), U.p, out,
+                                                  ascale / (double)MF_F16_SCALE, 0.0, partial.p, partial_o2.p, plan_d.p, 1, viol_d.p, E, ntr)));
             MMW_TRY(kend());
             planes_ready[0] = false;
+            planes0_f16 = false;
             start_colsq_ready = false;
             return MMW_OK;
         }

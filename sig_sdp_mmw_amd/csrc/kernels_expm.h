@@ -29,6 +29,7 @@ struct ExpmPlan {      // written by k_plan, read by every expm kernel
     int apost;         // 1: the Lanczos steps carry an a-posteriori error estimate and stop as soon as it meets tol
     int m_eff;         // steps the last application actually used (written by the combination)
     int mfma_ok;       // 1: the two-half bf16 split of the matrix-core SpMM (kernels_mfma.h) keeps the product within tol
+    int f16_ok;        // 1: so does the first-order product's single fp16 plane of u: 2^-12 max_i sum_j |a_ij| <= tol
     double absn;       // max_i sum_j |a_ij| of the scaled matrix (the bound behind mfma_ok)
     // Lagged planning (the loop's optimistic chunks): the row sums of the matrix are made one iteration late, inside the DUAL
     // pass that reads the same rows, and the bounds for the matrix that is multiplied are extrapolated from the last two
@@ -1412,6 +1413,7 @@ __device__ __forceinline__ void plan_body(int K, int method, int max_order, doub
         // matrix-core SpMM: ||dT||_F <= 3 * 2^-17 || |A| ||_2 ||U||_F and || |A| ||_2 <= max_i sum_j |a_ij| = max(pp, pm)
         p.absn = pp > pm ? pp : pm;
         p.mfma_ok = 2.3e-5 * p.absn <= tol ? 1 : 0;
+        p.f16_ok = 2.4415e-4 * p.absn <= tol && p.absn < 0.03 ? 1 : 0;  // 2^-12; and the entries times 2^20 stay inside fp16's range
         // the a-posteriori stop needs the shifted recurrence of the half-tile SpMM, a single substep and a geometric tail
         p.apost = apost && method == 0 && nsub == 1 && !p.overflow && r < 0.5;
         for (int i = 0; i < MAX_ORDER + 2; ++i) p.conv[i] = 0u;  // identity of the maximum; a step's entry is read only after its k_lz_scalars ran

@@ -39,11 +39,12 @@ template <typename T> struct SketchArgs {
     T* R;
     double* colsq_part;
     unsigned short* planes;  // optional (fp32 only): bf16 hi plane, then the lo plane K * Dpad elements further (kernels_mfma.h)
+    int planes_f16;          // 1: ONE fp16 plane instead (the first-order product's operand)
 };
 template <typename T, int NWAVES>
 __device__ __forceinline__ void sketch_rows(int K, int D, int Dpad, uint64_t seed, uint32_t iter, T* __restrict__ R,
                                             double* __restrict__ colsq_part, int bid, int nblocks, double* shc,
-                                            unsigned short* __restrict__ planes = nullptr);
+                                            unsigned short* __restrict__ planes = nullptr, int planes_f16 = 0);
 
 // ---- DUAL, step 1: per row r[k] = sum of off-diagonal X, eD; per pair eF -------------------------
 template <typename T>
@@ -322,13 +323,13 @@ __global__ __launch_bounds__(BLOCK) void k_loss(PatternDev<T> P, const int* __re
                                                 unsigned* __restrict__ afrag = nullptr, T* __restrict__ Ynorm = nullptr,
                                                 T* __restrict__ yavg = nullptr, int accumulate = 0, PlanArgs pa = PlanArgs{},
                                                 long long* __restrict__ rs_zero = nullptr /* fixed-point totals the coming product / SDDMM add to */,
-                                                int rs_zero_n = 0) {
+                                                int rs_zero_n = 0, int afrag_f16 = 0 /* 1: the image feeds the first-order product (split_f16_scaled) */) {
     // Ynorm != nullptr: Y and wH hold the unnormalised exponentials of the fused DUAL pass (k_dual_h, mref form) and scal[3]
     // their total; this pass divides where it uses them and writes the normalised Y (and its running sum) on the side.
     if ((int)blockIdx.x < sk.nblocks) {  // leading workgroups draw this iteration's sketch (same shape as k_sketch_rng: same bits)
         extern __shared__ __attribute__((aligned(16))) char smem_raw[];
         sketch_rows<T, WAVES_PER_BLOCK>(sk.K, sk.D, Dpad, sk.seed, sk.iter, sk.R, sk.colsq_part, (int)blockIdx.x, sk.nblocks,
-                                        reinterpret_cast<double*>(smem_raw), sk.planes);
+                                        reinterpret_cast<double*>(smem_raw), sk.planes, sk.planes_f16);
         return;
     }
     const int lead = sk.nblocks + (pa.plan ? 1 : 0);
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(BLOCK) void k_loss(PatternDev<T> P, const int* __re
         const T nv = (T)((double)lval[e] - eta * add);
         lval[e] = nv;
         if (bpos) lval_blk[bpos[e]] = nv;  // the same value in the LDS-staged kernel's traversal order
-        if (fpos) afrag[fpos[e]] = split_bf16((float)nv);  // and as two bf16 halves in the matrix-core kernel's fragment order
+        if (fpos) afrag[fpos[e]] = afrag_f16 ? split_f16_scaled((float)nv) : split_bf16((float)nv);  // and as two 16-bit halves in the matrix-core kernel's fragment order
         if (xavg) xavg[e] += xval[e];  // the previous iteration's X joins the running sum here (same index space, one pass fewer)
     }
 }
@@ -819,7 +820,7 @@ __device__ __forceinline__ void normals16(const uint32_t (&w)[4], double (&n)[2]
 template <typename T, int NWAVES>
 __device__ __forceinline__ void sketch_rows(int K, int D, int Dpad, uint64_t seed, uint32_t iter, T* __restrict__ R,
                                             double* __restrict__ colsq_part, int bid, int nblocks, double* shc,
-                                            unsigned short* __restrict__ planes) {
+                                            unsigned short* __restrict__ planes, int planes_f16) {
     constexpr int VEC = V16<T>::N;
     constexpr int NS = 4;  // 64 lanes x 4 steps x 16 B covers Dpad <= 1024 floats / 512 doubles
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -865,7 +866,11 @@ __device__ __forceinline__ void sketch_rows(int K, int D, int Dpad, uint64_t see
                 }
                 store16(R + (size_t)row * Dpad + (size_t)p * VEC, n[i]);
                 if constexpr (sizeof(T) == 4) {
-                    if (planes) {  // the matrix-core SpMM reads the block as two bf16 halves: made here, while the values are in registers
+                    if (planes && planes_f16) {  // the first-order product reads ONE fp16 plane
+                        const size_t o = ((size_t)row * Dpad + (size_t)p * VEC) >> 2;
+                        reinterpret_cast<uint2*>(planes)[o] = make_uint2((unsigned)f16_rn(n[i][0]) | ((unsigned)f16_rn(n[i][1]) << 16),
+                                                                         (unsigned)f16_rn(n[i][2]) | ((unsigned)f16_rn(n[i][3]) << 16));
+                    } else if (planes) {  // the matrix-core SpMM reads the block as two bf16 halves: made here, while the values are in registers
                         const unsigned a = split_bf16(n[i][0]), b = split_bf16(n[i][1]), c = split_bf16(n[i][2]), d = split_bf16(n[i][3]);
                         const size_t o = ((size_t)row * Dpad + (size_t)p * VEC) >> 2;
                         reinterpret_cast<uint2*>(planes)[o] = make_uint2((a >> 16) | (b & 0xFFFF0000u), (c >> 16) | (d & 0xFFFF0000u));
@@ -895,9 +900,9 @@ __device__ __forceinline__ void sketch_rows(int K, int D, int Dpad, uint64_t see
 
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_sketch_rng(int K, int D, int Dpad, uint64_t seed, uint32_t iter, T* __restrict__ R,
-                                                      double* __restrict__ colsq_part, unsigned short* __restrict__ planes = nullptr) {
+                                                      double* __restrict__ colsq_part, unsigned short* __restrict__ planes = nullptr, int planes_f16 = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    sketch_rows<T, WAVES_PER_BLOCK>(K, D, Dpad, seed, iter, R, colsq_part, blockIdx.x, gridDim.x, reinterpret_cast<double*>(smem_raw), planes);
+    sketch_rows<T, WAVES_PER_BLOCK>(K, D, Dpad, seed, iter, R, colsq_part, blockIdx.x, gridDim.x, reinterpret_cast<double*>(smem_raw), planes, planes_f16);
 }
 
 // fragment image of the matrix-core SpMM rebuilt from the CSR values (after a snapshot restore)

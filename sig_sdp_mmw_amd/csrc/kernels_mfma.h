@@ -89,9 +89,34 @@ struct MfEpi {
 };
 // a chunk = KC k-steps: per k-step the B image (2 planes x 16 rows x the group's columns), then the A fragments of all KC steps
 // GT = column tiles per workgroup
-template <int MT, int GT, int KC> constexpr int mf_chunk_bytes() { return KC * (2048 * GT + 2048 * MT); }
+// PL = planes of the B operand: 2 (bf16 hi / lo) or 1 (one fp16 plane: the first-order product, below)
+template <int MT, int GT, int KC, int PL = 2> constexpr int mf_chunk_bytes() { return KC * (1024 * PL * GT + 2048 * MT); }
 // NB = chunks resident in LDS (one being multiplied, NB - 1 in flight)
-template <int MT, int GT, int KC, int NB> constexpr int mf_lds_bytes() { return MF_UNION_ROWS * 4 + 64 * 4 + NB * mf_chunk_bytes<MT, GT, KC>(); }
+template <int MT, int GT, int KC, int NB, int PL = 2> constexpr int mf_lds_bytes() { return MF_UNION_ROWS * 4 + 64 * 4 + NB * mf_chunk_bytes<MT, GT, KC, PL>(); }
+constexpr int mf_planes(int mode) { return mode == SPMM_FIRST ? 1 : 2; }
+typedef _Float16 mf_h8 __attribute__((ext_vector_type(8)));
+// The first-order product runs on fp16 operands: its result o = A'u enters y = u + o at q = ||A'u|| / ||u|| ~ 1e-4, so ONE fp16 plane of u
+// (11 significant bits: ||d o|| <= 2^-12 || |A| ||_2 ||u||, ExpmPlan::f16_ok) replaces the two bf16 halves -- half the gather, two products
+// per tile and k-step instead of three.  The matrix keeps two halves (fp16 hi + fp16 lo of the entry times 2^20: entries of L are ~1e-5,
+// below fp16's normal range; the scale is taken out again with `ascale`).
+constexpr float MF_F16_SCALE = 1048576.0f;
+__device__ __forceinline__ unsigned short f16_rn(float x) { return __builtin_bit_cast(unsigned short, (_Float16)x); }
+__device__ __forceinline__ float f16_f32(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
+// x * 2^20 ~= hi + lo in fp16, returned as hi << 16 | lo (the matrix image's word)
+__device__ __forceinline__ unsigned split_f16_scaled(float x) {
+    const float xs = x * MF_F16_SCALE;
+    const unsigned short hi = f16_rn(xs);
+    const unsigned short lo = f16_rn(xs - f16_f32(hi));
+    return ((unsigned)hi << 16) | (unsigned)lo;
+}
+// one fp16 plane of an fp32 block (the first-order product's B operand, when the block's producer did not write it)
+__global__ __launch_bounds__(BLOCK) void k_plane_f16(size_t n4, const float4* __restrict__ src, uint2* __restrict__ dst) {
+    for (size_t o = (size_t)blockIdx.x * BLOCK + threadIdx.x; o < n4; o += (size_t)gridDim.x * BLOCK) {
+        const float4 x = src[o];
+        dst[o] = make_uint2((unsigned)f16_rn(x.x) | ((unsigned)f16_rn(x.y) << 16), (unsigned)f16_rn(x.z) | ((unsigned)f16_rn(x.w) << 16));
+    }
+}
+
 
 // s_waitcnt vmcnt(n) for a wave-uniform n known only at run time (the instruction takes an immediate)
 __device__ __forceinline__ void mf_wait_vmcnt(int n) {
@@ -125,6 +150,7 @@ void k_spmm_mfma(MfmaDev M, int Dpad, size_t plane_bytes, const char* __restrict
                  const ExpmPlan* __restrict__ plan, int step, int* __restrict__ viol, unsigned long long* __restrict__ stamps, MfEpi E) {
     static_assert(MODE == SPMM_PLAIN || MODE == SPMM_LANCZOS || MODE == SPMM_AXPBY || MODE == SPMM_FIRST, "the matrix-core SpMM has the plain, the Lanczos, the AXPBY and the first-order epilogue");
     static_assert(MF_KPAD % KC == 0, "the fragment image pads a block's k-steps to whole chunks");
+    constexpr bool F16 = MODE == SPMM_FIRST;  // one fp16 plane of u, fp16 hi / lo of the matrix (see MF_F16_SCALE)
     // diagnostic runs only (stamps != nullptr): shader-clock sums per wave {prologue, wait + barrier, DMA issue, products, epilogue, steps}
     unsigned long long tk0 = 0, tk1 = 0, acc_wait = 0, acc_issue = 0, acc_comp = 0, t_pro = 0;
     if (stamps) tk0 = __builtin_amdgcn_s_memtime();
@@ -141,15 +167,16 @@ void k_spmm_mfma(MfmaDev M, int Dpad, size_t plane_bytes, const char* __restrict
             shift_d = plan->mu;
         } else if (step > plan->m) return;
         // launched without a plan readback on a matrix whose norm has outgrown the two-half split: the chunk is replayed on the fp32 kernel
-        if (!plan->mfma_ok && viol && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *viol = 1;
+        if (!(F16 ? plan->f16_ok : plan->mfma_ok) && viol && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *viol = 1;
     }
     const float ascale = (float)ascale_d, shift = (float)shift_d;
     static_assert(NW % MS == 0 && MT % MS == 0, "row tiles and waves split evenly");
     constexpr int NWN = NW / MS;   // waves side by side along the columns
     constexpr int MTW = MT / MS;   // row tiles per wave
     constexpr int GT = NWN * NT;   // column tiles (32 columns, 64 bytes per plane row) per workgroup
-    constexpr int CHUNK = mf_chunk_bytes<MT, GT, KC>();
-    constexpr int B1 = 2048 * GT;      // B image of one k-step (at the group's full width)
+    constexpr int PL = mf_planes(MODE);
+    constexpr int CHUNK = mf_chunk_bytes<MT, GT, KC, PL>();
+    constexpr int B1 = 1024 * PL * GT;  // B image of one k-step (at the group's full width)
     constexpr int A_OFF = KC * B1;     // the A fragments sit behind the B images of the chunk
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     int* un_l = reinterpret_cast<int*>(smem_raw);                         // [MF_UNION_ROWS] union column ids
@@ -183,8 +210,8 @@ void k_spmm_mfma(MfmaDev M, int Dpad, size_t plane_bytes, const char* __restrict
     // runs of the B image (64 slots of 16 bytes: slot -> plane, row, 16-byte piece of the row) and pieces [2 ng, 2 ng + 2 MT) the
     // A fragment halves.  Both kinds share one address form, src = base + un_l[16 KC c + row] * mul + c * step (B: mul = row
     // pitch, step = 0; A: mul = 0), so the issue loop has no branch but the piece count.
-    constexpr int NJ = (KC * (2 * GT + 2 * MT) + NW - 1) / NW;
-    const int nB1 = 2 * ng, nP1 = nB1 + 2 * MT, nI = KC * nP1;
+    constexpr int NJ = (KC * (PL * GT + 2 * MT) + NW - 1) / NW;
+    const int nB1 = PL * ng, nP1 = nB1 + 2 * MT, nI = KC * nP1;
     const int cw = wv < nI ? (nI - wv + NW - 1) / NW : 0;  // pieces of this wave per chunk
     const char* pbase[NJ];
     unsigned pmul[NJ];
@@ -202,7 +229,7 @@ void k_spmm_mfma(MfmaDev M, int Dpad, size_t plane_bytes, const char* __restrict
         pdst[j] = 0;
         if (i < nI && i1 < nB1) {
             const int slot = i1 * 64 + lane;
-            const int p = slot >= MF_KROWS * spr ? 1 : 0, rem = slot - p * (MF_KROWS * spr);
+            const int p = (PL == 2 && slot >= MF_KROWS * spr) ? 1 : 0, rem = slot - p * (MF_KROWS * spr);
             const int r = mf_div(rem, spr, rspr), t = rem - r * spr;
             int G = (t >> 2) - rot(r & 3);
             if (G < 0) G += ng;
@@ -292,15 +319,24 @@ void k_spmm_mfma(MfmaDev M, int Dpad, size_t plane_bytes, const char* __restrict
                 const char* p0 = bb + rbase[i];
                 const mf_s4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p0));
                 const mf_s4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p0 + row4));
-                const mf_s4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p0 + plane_l));
-                const mf_s4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p0 + plane_l + row4));
-                const mf_s8 bhi = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-                const mf_s8 blo = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                if constexpr (F16) {
+                    const mf_s8 bh = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
 #pragma unroll
-                for (int m = 0; m < MTW; ++m) {
-                    acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mf_bf8, alo[m]), __builtin_bit_cast(mf_bf8, bhi), acc[m][i], 0, 0, 0);
-                    acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mf_bf8, ahi[m]), __builtin_bit_cast(mf_bf8, blo), acc[m][i], 0, 0, 0);
-                    acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mf_bf8, ahi[m]), __builtin_bit_cast(mf_bf8, bhi), acc[m][i], 0, 0, 0);
+                    for (int m = 0; m < MTW; ++m) {
+                        acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mf_h8, alo[m]), __builtin_bit_cast(mf_h8, bh), acc[m][i], 0, 0, 0);
+                        acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mf_h8, ahi[m]), __builtin_bit_cast(mf_h8, bh), acc[m][i], 0, 0, 0);
+                    }
+                } else {
+                    const mf_s4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p0 + plane_l));
+                    const mf_s4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p0 + plane_l + row4));
+                    const mf_s8 bhi = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                    const mf_s8 blo = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m) {
+                        acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mf_bf8, alo[m]), __builtin_bit_cast(mf_bf8, bhi), acc[m][i], 0, 0, 0);
+                        acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mf_bf8, ahi[m]), __builtin_bit_cast(mf_bf8, blo), acc[m][i], 0, 0, 0);
+                        acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mf_bf8, ahi[m]), __builtin_bit_cast(mf_bf8, bhi), acc[m][i], 0, 0, 0);
+                    }
                 }
             }
         }

@@ -795,6 +795,8 @@ template <typename T> struct Solver final : mmw_solver {
         union { unsigned u; float f; } e;
         e.u = p.first_est;
         const double grow = std::pow((double)(iter + ahead + 1) / (double)std::max(iter, 1), 2.0);
+        // ... and the single fp16 plane of u must stay admissible over the chunk (ExpmPlan::f16_ok; the norm grows linearly)
+        if (!(2.4415e-4 * p.absn * std::sqrt(grow) <= p.tol) || !(p.absn * std::sqrt(grow) < 0.03)) return false;
         return (double)e.f <= p.tol / 8.0 && (double)e.f * grow <= p.tol / 2.0;
     }
     int next_launch_order(int ahead = 0) const {
@@ -841,13 +843,14 @@ template <typename T> struct Solver final : mmw_solver {
         return (double)e.f <= p.tol / 2.0;
     }
     int sketch_slabs() const { static const int cap = getenv("MMW_SK_SLABS") ? atoi(getenv("MMW_SK_SLABS")) : 256; return std::min(grid_rows(K), cap); }  // few slabs for the start-norm reduction
-    int launch_sketch(hipStream_t s, uint64_t seed, uint32_t it) {
+    int launch_sketch(hipStream_t s, uint64_t seed, uint32_t it, bool planes_f16 = false) {
         const bool lz = eng.method == MMW_EXPM_LANCZOS;
         const int Dpad = eng.lay.Dpad;
         unsigned short* pl = eng.start_planes();
         hipLaunchKernelGGL((k_sketch_rng<T>), dim3(sketch_slabs()), dim3(BLOCK), lz ? (size_t)WAVES_PER_BLOCK * Dpad * sizeof(double) : 0, s, K, D, Dpad,
-                           seed, it, eng.start_block(), lz ? eng.partial_sq.p : (double*)nullptr, pl);
+                           seed, it, eng.start_block(), lz ? eng.partial_sq.p : (double*)nullptr, pl, planes_f16 ? 1 : 0);
         eng.planes_ready[0] = pl != nullptr;
+        eng.planes0_f16 = planes_f16 && pl != nullptr;
         MMW_HIP(hipGetLastError());
         return MMW_OK;
     }
@@ -920,6 +923,10 @@ template <typename T> struct Solver final : mmw_solver {
             MMW_TRY(kt.begin(KT_LOSS));
             // the X of the previous iteration of this chunk is added to the running sum inside this pass (xavg_deferred), and
             // this iteration's sketch is drawn by leading workgroups of the same launch (VALU work under a memory-bound pass)
+            const bool rs_zeroed = rs_enabled && rsfx.p != nullptr && sddmm_mfma;  // the coming SDDMM may add its row sums to zeroed totals
+            // the exponential of this iteration as one first-order product (decided per chunk, first_order_ok)
+            const bool first_it = optimistic && first_guess && m_launch == 1 && !randv && rs_zeroed && sizeof(T) == 4 && eng.mfma_now() &&
+                                  eng.method == MMW_EXPM_LANCZOS && eng.use_blk && (Dpad % 32) == 0;
             SketchArgs<T> skl{};
             const bool lz_m = eng.method == MMW_EXPM_LANCZOS;
             const bool sketch_have = !randv && sketch_done_for == (int64_t)iter && sketch_done_seed == seed;
@@ -928,23 +935,21 @@ template <typename T> struct Solver final : mmw_solver {
                 skl.R = eng.start_block();
                 skl.colsq_part = lz_m ? eng.partial_sq.p : nullptr;
                 skl.planes = eng.start_planes();
+                skl.planes_f16 = first_it ? 1 : 0;
                 eng.planes_ready[0] = skl.planes != nullptr;
+                eng.planes0_f16 = first_it && skl.planes != nullptr;
                 sketch_done_for = (int64_t)iter; sketch_done_seed = seed; sketch_done_slabs = skl.nblocks;
             }
             // the blocked copy of L feeds the fp32 LDS kernel only: while the matrix-core kernel runs the products it is left stale
             const bool mf_it = eng.mfma_now() && eng.method == MMW_EXPM_LANCZOS;
             if (mf_it) lblk_stale = true;
-            const bool rs_zeroed = rs_enabled && rsfx.p != nullptr && sddmm_mfma;  // the coming SDDMM may add its row sums to zeroed totals
-            // the exponential of this iteration as one first-order product (decided per chunk, first_order_ok)
-            const bool first_it = optimistic && first_guess && m_launch == 1 && !randv && rs_zeroed && sizeof(T) == 4 && eng.mfma_now() &&
-                                  eng.method == MMW_EXPM_LANCZOS && eng.use_blk && (Dpad % 32) == 0;
             const PlanArgs pl_loss = fused_dual ? pa : PlanArgs{};  // the fused pass has no softmax pass B to lend the planning a workgroup
             hipLaunchKernelGGL((k_loss<T>), dim3(gl + skl.nblocks + (pl_loss.plan ? 1 : 0)), dim3(BLOCK), skl.nblocks && lz_m ? (size_t)WAVES_PER_BLOCK * Dpad * sizeof(double) : 0,
                                st, P, d_lrow.p, fused_dual ? yun.p : Y.p, wH.p, scal.p, lval.p, eta,
                                (const int*)(eng.use_blk && !mf_it ? b_bpos.p : nullptr), lval_blk.p,
                                (const T*)(xavg_deferred ? xval.p : nullptr), xavg_deferred ? xavg.p : (T*)nullptr, skl, Dpad,
                                (const int*)(eng.use_mfma ? b_fpos.p : nullptr), afrag.p, fused_dual ? Y.p : (T*)nullptr, yavg.p, acc, pl_loss,
-                               rs_zeroed ? rsfx.p : (long long*)nullptr, rs_zeroed ? (first_it ? 2 * K : K) : 0);
+                               rs_zeroed ? rsfx.p : (long long*)nullptr, rs_zeroed ? (first_it ? 2 * K : K) : 0, first_it ? 1 : 0);
             xavg_deferred = false;
             MMW_TRY(kt.end());
             MMW_TRY(record(2));
@@ -958,7 +963,7 @@ template <typename T> struct Solver final : mmw_solver {
                 last_was_rng = false;
             } else {
                 const bool have = sketch_done_for == (int64_t)iter && sketch_done_seed == seed;  // drawn by the previous SDDMM launch
-                if (!have) MMW_TRY(launch_sketch(st, seed, (uint32_t)iter));
+                if (!have) MMW_TRY(launch_sketch(st, seed, (uint32_t)iter, first_it));
                 eng.start_colsq_ready = eng.method == MMW_EXPM_LANCZOS;  // the Lanczos start norms come out of the sketch kernel
                 eng.npart_start = have ? sketch_done_slabs : sketch_slabs();
                 sketch_done_for = -1;
@@ -1050,7 +1055,9 @@ template <typename T> struct Solver final : mmw_solver {
                     sk.R = eng.start_block();
                     sk.colsq_part = lzm ? eng.partial_sq.p : nullptr;
                     sk.planes = eng.start_planes();
+                    sk.planes_f16 = 0;
                     eng.planes_ready[0] = sk.planes != nullptr;
+                    eng.planes0_f16 = false;
                     sketch_done_for = (int64_t)iter + 1;
                     sketch_done_seed = seed;
                     sketch_done_slabs = sk.nblocks * VBW;
