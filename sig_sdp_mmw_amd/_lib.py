@@ -195,7 +195,7 @@ class Solver:
             {"name": "k_spmm_blk (LDS-staged locality-blocked CSR SpMM, 256-byte tiles)", "limiter": "VALU issue + LDS latency"},
             {"name": "k_spmm_blk2 (LDS-staged locality-blocked CSR SpMM, 128-byte half tiles)",
              "limiter": "VALU issue + LDS latency; operands live in L2 / Infinity Cache, not HBM"},
-            {"name": "k_spmm_mfma (locality blocks as dense bf16 hi/lo products on the matrix cores)",
+            {"name": "k_spmm_mfma (locality blocks as dense bf16 hi/lo -- first-order form: fp16 -- products on the matrix cores)",
              "limiter": "gather of the blocks' union rows into LDS at the CU's L2 rate; operands live in L2 / Infinity Cache, not HBM"},
         ][kind]
 

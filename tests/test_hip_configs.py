@@ -216,18 +216,23 @@ def test_full_size_exponential_meets_the_tolerance_when_stopped_early(eta, nit):
     s.close()
 
 
-def test_full_size_first_order_exponential_meets_the_tolerance():
-    """journal N=10 003, D=372, fp32: the last iteration of a chunked run takes exp(L/2)R as one first-order product (it leaves the fp32
-    copy with the factor e^mu the product itself drops); against scipy's expm_multiply on the same L and sketch, first 24 columns."""
+@pytest.mark.parametrize("eta,nit,expect_first", [(0.04, 120, True), (0.4, 60, False)])
+def test_full_size_first_order_exponential_meets_the_tolerance(eta, nit, expect_first):
+    """journal N=10 003, D=372, fp32: the last iteration of a chunked run takes exp(L/2)R as one first-order product on fp16 operands (it
+    leaves the fp32 copy with the factor e^mu the product itself drops); against scipy's expm_multiply on the same L and sketch, first
+    24 columns.  With eta = 0.4 the norm outgrows what the single fp16 plane of u may carry (ExpmPlan::f16_ok) and what one step may
+    (the bound): the chunks go back to Lanczos steps by themselves, and whatever form the last iteration took meets the tolerance."""
     from scipy.sparse.linalg import expm_multiply
     state, Z = journal_graph(28, 0.0319, 0), 186
-    nit = 120
-    s = _lib.Solver(Z, state, nit + 1, 0.04, dtype=_lib.F32)
+    s = _lib.Solver(Z, state, nit + 1, eta, dtype=_lib.F32)
     s.set_expm(_lib.EXPM_LANCZOS, 12, 1e-6)
     s.iterate(nit, None, seed=11)
     s.sync()
     first = s.read(_lib.F_DUAL_INFO)[2]
-    assert first >= nit // 2 and s.read(_lib.F_BLOCKING)[3] == 0, (first, s.read(_lib.F_BLOCKING))
+    if expect_first:
+        assert first >= nit // 2 and s.read(_lib.F_BLOCKING)[3] == 0, (first, s.read(_lib.F_BLOCKING))
+    else:
+        assert first < nit // 2, first
     ip, ix = s.read_i32(_lib.I_L_INDPTR), s.read_i32(_lib.I_L_INDICES)
     K = s.K
     L = scipy.sparse.csr_matrix((s.read(_lib.F_LVAL), ix, ip), shape=(K, K))
