@@ -181,7 +181,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="journal-1pct", choices=sorted(WORKLOADS))
     ap.add_argument("--instances-per-gpu", type=int, default=1, help="resident handles per rank, iterations enqueued round-robin (configs[3]: 8)")
-    ap.add_argument("--instance-threads", action="store_true", help="with --instances-per-gpu M: one host thread per instance instead of round-robin calls")
+    ap.add_argument("--instance-threads", action="store_true", help="(default with --instances-per-gpu M > 1) one host thread per instance")
+    ap.add_argument("--no-instance-threads", action="store_true", help="with --instances-per-gpu M: one host thread enqueues all instances round-robin")
     ap.add_argument("--expm", default="lanczos", choices=["lanczos", "taylor"])
     ap.add_argument("--dtype", default=None, choices=["f32", "f64"])
     ap.add_argument("--eta", type=float, default=0.04)
@@ -259,9 +260,10 @@ def main():
         if len(solvers) == 1:
             solvers[0].iterate(n, None, seeds[0])
             solvers[0].sync()
-        elif args.instance_threads:
+        elif not args.no_instance_threads:
             # one host thread per resident instance: the launches of a step are ~20 small kernels, and one thread enqueues ~10 k
-            # iterations per second whatever the GPU could overlap (the library calls release the GIL)
+            # iterations per second whatever the GPU could overlap (the library calls release the GIL).  Measured on one MI355X:
+            # er-5pct-2k x 8: 7 230 -> 7 680 it/s; journal-native x 4: 22 800 -> 26 500 it/s
             def one(s, sd):
                 s.iterate(n, None, sd)
                 s.sync()
