@@ -90,6 +90,27 @@ template <typename T> struct Solver final : mmw_solver {
     DevBuf<double> tr1_part; // trace shares of the first-order product's workgroups (zero where none works)
     const bool first_enabled = getenv("MMW_NO_FIRST_ORDER") == nullptr;
     bool first_guess = false;  // the chunk being enqueued takes the first-order exponential (first_order_ok at its start)
+    int age0 = 0;              // iterations L_accu had accumulated when this run started (a warm restart continues it): the matrix's norm and
+                               // every estimate derived from it grow with age() = age0 + iter, not with the run's own counter
+    int age() const { return age0 + iter; }
+    // Growth of the matrix's norm bound over the coming `ahead` iterations, as a ratio: at least linear in the age, and at least what
+    // the last two plans read back in this run showed (after a warm restart with fewer slots the violations -- and with them the
+    // increments of L -- are larger than the age suggests), with a factor 1.5 on that slope.
+    double rho_prev = 0.0, rho_last = 0.0;
+    int age_prev = -1, age_last = -1;
+    bool warm_fresh = false;  // no chunk of this warm-started run has been settled yet: its first chunk is short and carries a spare step
+    void note_plan() {  // a plan has just been read back (settle): remember the bound and the age it belongs to
+        if (age_last >= 0 && age() > age_last) { rho_prev = rho_last; age_prev = age_last; }
+        rho_last = eng.last.rho; age_last = age();
+    }
+    double growth_ratio(int ahead) const {
+        double r = (double)(age() + ahead + 1) / (double)std::max(age(), 1);
+        if (age_prev >= 0 && age_last > age_prev && rho_last > 0.0 && rho_last > rho_prev) {
+            const double slope = (rho_last - rho_prev) / (double)(age_last - age_prev);
+            r = std::max(r, (rho_last + 1.5 * slope * (double)(ahead + 1)) / rho_last);
+        }
+        return r;
+    }
     long long n_first_iters = 0;
     bool rs_last = false;    // the last iteration enqueued left rsfx for the X the next one starts from
     const bool rs_enabled = getenv("MMW_NO_SDDMM_ROWSUMS") == nullptr;
@@ -112,6 +133,7 @@ template <typename T> struct Solver final : mmw_solver {
     Extras<T> extras;
     KernelTimers kt;
     std::vector<hipEvent_t> events;  // 4 per timed iteration
+    std::vector<hipEvent_t> event_pool;  // events of earlier runs, kept for reuse
     std::vector<double> phase_us;
     uint64_t last_seed = 0;
     bool last_was_rng = false;
@@ -121,6 +143,7 @@ template <typename T> struct Solver final : mmw_solver {
         if (host_only) return;
         (void)hipSetDevice(device);
         for (auto e : events) (void)hipEventDestroy(e);
+        for (auto e : event_pool) (void)hipEventDestroy(e);
         if (st) (void)hipStreamDestroy(st);
     }
 
@@ -633,7 +656,10 @@ template <typename T> struct Solver final : mmw_solver {
     int restart_warm(int32_t nit_) {
         if (nit_ < 1) return fail(MMW_ERR_ARG, "nit must be >= 1");
         nit = nit_;
+        age0 += iter;
         iter = 0;
+        warm_fresh = true;
+        age_prev = age_last = -1;
         pending = false;
         chain_ok = false;
         if (eng.viol_d.p) MMW_TRY(eng.clear_violation());
@@ -650,6 +676,9 @@ template <typename T> struct Solver final : mmw_solver {
         if (nit_ < 1) return fail(MMW_ERR_ARG, "nit must be >= 1");
         nit = nit_;
         iter = 0;
+        age0 = 0;
+        warm_fresh = false;
+        age_prev = age_last = -1;
         pending = false;
         chain_ok = false;
         plan_seen = false;
@@ -678,7 +707,11 @@ template <typename T> struct Solver final : mmw_solver {
     int record(int slot) {
         if (!timing) return MMW_OK;
         hipEvent_t e;
-        MMW_HIP(hipEventCreate(&e));
+        if (!event_pool.empty()) {  // events are kept across runs: creating four per iteration cost the class path ~20 us per iteration
+            e = event_pool.back();
+            event_pool.pop_back();
+        } else
+            MMW_HIP(hipEventCreate(&e));
         MMW_HIP(hipEventRecord(e, st));
         events.push_back(e);
         (void)slot;
@@ -695,7 +728,7 @@ template <typename T> struct Solver final : mmw_solver {
             MMW_HIP(hipEventElapsedTime(&t, events[i], events[i + 3]));
             phase_us.push_back(a * 1e3); phase_us.push_back(b * 1e3); phase_us.push_back(c * 1e3); phase_us.push_back(t * 1e3);
         }
-        for (auto e : events) (void)hipEventDestroy(e);
+        for (auto e : events) event_pool.push_back(e);
         events.clear();
         return MMW_OK;
     }
@@ -732,6 +765,7 @@ template <typename T> struct Solver final : mmw_solver {
         MMW_TRY(eng.fetch_plan(&viol));
         if (!viol) {
             plan_seen = true;
+            note_plan();
             m_guess = next_launch_order();
             return MMW_OK;
         }
@@ -742,7 +776,7 @@ template <typename T> struct Solver final : mmw_solver {
         iter = pend_iter0;
         if (timing) {  // drop the timers of the discarded chunk (earlier chunks keep theirs)
             MMW_HIP(hipStreamSynchronize(st));
-            for (size_t i = pend_events0; i < events.size(); ++i) (void)hipEventDestroy(events[i]);
+            for (size_t i = pend_events0; i < events.size(); ++i) event_pool.push_back(events[i]);
             events.resize(std::min(events.size(), pend_events0));
         }
         return iterate_impl(pend_n, nullptr, pend_seed, false);
@@ -767,14 +801,20 @@ template <typename T> struct Solver final : mmw_solver {
         while (left > 0) {
             MMW_TRY(settle());
             // ... or as many as the last settled plan's estimate leaves room for (room_iterations)
-            int cap = lagged_ok() ? std::max(8, std::min(32, (int)iter)) : std::max(4, std::min(32, (int)iter / 2));
-            if (chain_ok && iter >= 4) cap = std::max(cap, std::min(32, room_iterations()));
+            int cap = lagged_ok() ? std::max(8, std::min(32, age())) : std::max(4, std::min(32, age() / 2));
+            if (chain_ok && age() >= 4) cap = std::max(cap, std::min(32, room_iterations()));
+            if (warm_fresh) cap = 8;
             const int chunk = std::min(left, cap);
             if (plan_seen) m_guess = next_launch_order(chunk);  // before the first readback of a run: the default set by reset()
             first_guess = plan_seen && m_guess == 1 && first_order_ok(chunk);
+            if (warm_fresh) {  // the plan at hand belongs to the previous probe's slot count: one spare step, no first-order form
+                m_guess = std::min(eng.max_order, std::max(2, eng.last.m_eff + 1));
+                first_guess = false;
+            }
             MMW_TRY(copy_state(true));
             pend_iter0 = iter; pend_n = chunk; pend_seed = seed; pend_events0 = events.size();
             MMW_TRY(iterate_impl(chunk, nullptr, seed, chunk > 1));
+            warm_fresh = false;
             pending = chunk > 1;
             left -= chunk;
         }
@@ -794,7 +834,7 @@ template <typename T> struct Solver final : mmw_solver {
         if (!first_enabled || sizeof(T) != 4 || !p.apost || p.m_eff != 1 || p.first_est == 0u) return false;
         union { unsigned u; float f; } e;
         e.u = p.first_est;
-        const double grow = std::pow((double)(iter + ahead + 1) / (double)std::max(iter, 1), 2.0);
+        const double grow = std::pow(growth_ratio(ahead), 2.0);
         // ... and the single fp16 plane of u must stay admissible over the chunk (ExpmPlan::f16_ok; the norm grows linearly)
         if (!(2.4415e-4 * p.absn * std::sqrt(grow) <= p.tol) || !(p.absn * std::sqrt(grow) < 0.03)) return false;
         return (double)e.f <= p.tol / 8.0 && (double)e.f * grow <= p.tol / 2.0;
@@ -806,7 +846,7 @@ template <typename T> struct Solver final : mmw_solver {
         if (p.apost && p.m_eff >= 1 && p.m_eff <= MAX_ORDER) {
             union { unsigned u; float f; } e;
             e.u = p.conv[p.m_eff];
-            const double grow = std::pow((double)(iter + ahead + 1) / (double)std::max(iter, 1), 2.0 * p.m_eff);
+            const double grow = std::pow(growth_ratio(ahead), 2.0 * p.m_eff);
             if ((double)e.f <= p.tol / 8.0 && (double)e.f * grow <= p.tol / 2.0) spare = 0;
         }
         if (p.m_eff >= p.m_apriori) spare = 0;  // the a-priori order is never exceeded
@@ -821,7 +861,9 @@ template <typename T> struct Solver final : mmw_solver {
         union { unsigned u; float f; } e;
         e.u = p.conv[1];
         if (!((double)e.f > 0.0)) return 32;
-        const double c = 0.5 * (double)iter * (std::sqrt(p.tol / (double)e.f) - 1.0);
+        double c = 0.5 * (double)age() * (std::sqrt(p.tol / (double)e.f) - 1.0);
+        if (age_prev >= 0 && age_last > age_prev && rho_last > rho_prev && rho_last > 0.0)  // ... or with the slope the last two plans showed (growth_ratio)
+            c = std::min(c, 0.5 * (std::sqrt(p.tol / (double)e.f) - 1.0) * rho_last * (double)(age_last - age_prev) / (1.5 * (rho_last - rho_prev)));
         return c > 32.0 ? 32 : (c < 0.0 ? 0 : (int)c);
     }
     // the last plan read back accepted ONE Lanczos step with a factor 8 to spare (where the order is already rising -- the graphs
@@ -862,7 +904,9 @@ template <typename T> struct Solver final : mmw_solver {
         const int gl = (int)std::min<size_t>(((size_t)H.nnzL() + BLOCK - 1) / BLOCK, (size_t)LOSS_GRID_MAX);  // LOSS: one thread per stored entry
         const int Dpad = eng.lay.Dpad;
         int m_launch = optimistic ? m_guess : 0;
-        const bool lag_chunk = optimistic && lagged_ok();  // from the plan the last settled chunk ended on
+        // from the plan the last settled chunk ended on; not in the first chunk after a warm restart: with another slot count the matrix grows
+        // at another rate than the history the extrapolation rests on (its bound was missed and the chunk replayed, measured)
+        const bool lag_chunk = optimistic && lagged_ok() && !warm_fresh;
         const bool chain = optimistic && chain_ok;          // this chunk continues the previous one (see chain_ok)
         chain_ok = false;
         // the plan is chained only while a single step is accepted with a factor 8 to spare: near a change of order an exact plan at
@@ -895,7 +939,7 @@ template <typename T> struct Solver final : mmw_solver {
             PlanArgs pa;
             if (lagged_it) {
                 pa.plan = eng.plan_d.p; pa.part = eng.row_part.p; pa.viol = eng.viol_d.p; pa.tol = eng.tol; pa.K = K; pa.method = eng.method;
-                pa.max_order = eng.max_order; pa.np = gr; pa.m_launch = m_launch; pa.apost = eng.apost() ? 1 : 0; pa.iter_seen = iter - 1;
+                pa.max_order = eng.max_order; pa.np = gr; pa.m_launch = m_launch; pa.apost = eng.apost() ? 1 : 0; pa.iter_seen = age() - 1;
             }
             // Inside a chunk (not its first iteration) the softmax rides in k_dual_h, shifted by the previous iteration's maximum
             // instead of this one's: one small workgroup then folds the sums, and the LOSS pass normalises where it reads
@@ -930,7 +974,10 @@ template <typename T> struct Solver final : mmw_solver {
             SketchArgs<T> skl{};
             const bool lz_m = eng.method == MMW_EXPM_LANCZOS;
             const bool sketch_have = !randv && sketch_done_for == (int64_t)iter && sketch_done_seed == seed;
-            if (!randv && !sketch_have && !kt_exact() && !timing && !getenv("MMW_NO_LOSS_SKETCH")) {
+            // (with the per-iteration phase events of mmw_set_timing on as well: the draw then counts into the LOSS phase's microseconds
+            // instead of the exponential's -- the reference draws inside mmw.py:172-181 -- and the iteration's total is unchanged; a launch of
+            // its own cost the class path 14 us per iteration)
+            if (!randv && !sketch_have && !kt_exact() && !getenv("MMW_NO_LOSS_SKETCH")) {
                 skl.nblocks = sketch_slabs(); skl.K = K; skl.D = D; skl.seed = seed; skl.iter = (uint32_t)iter;
                 skl.R = eng.start_block();
                 skl.colsq_part = lz_m ? eng.partial_sq.p : nullptr;
@@ -985,7 +1032,7 @@ template <typename T> struct Solver final : mmw_solver {
             eng.planes_only = eng.out_planes != nullptr && optimistic && it + 1 < n && !getenv("MMW_KEEP_XHALF");
             eng.rownorm_d = drow.p;  // the Lanczos combination also emits the row norms and the trace slabs
             eng.rownorm_part = tr_part.p;
-            eng.plan_iter = iter;
+            eng.plan_iter = age();
             int ntr1 = 0;
             if (first_it) {
                 const size_t need = (size_t)eng.first_grid_max();
@@ -1095,7 +1142,7 @@ template <typename T> struct Solver final : mmw_solver {
         if (optimistic && n > 1 && lag_chunk && eng.method == MMW_EXPM_LANCZOS) {
             // the chunk's last plan was extrapolated and no later plan of the chunk sees its matrix: check it here
             hipLaunchKernelGGL((k_rowsums<T>), dim3(eng.nwide), dim3(BLOCK), 0, st, K, d_indptr.p, d_col.p, lval.p, 0.5, eng.row_part.p);
-            hipLaunchKernelGGL(k_plan_verify, dim3(1), dim3(PLAN_THREADS), 0, st, K, eng.row_part.p, eng.nwide, eng.plan_d.p, eng.viol_d.p, iter - 1);
+            hipLaunchKernelGGL(k_plan_verify, dim3(1), dim3(PLAN_THREADS), 0, st, K, eng.row_part.p, eng.nwide, eng.plan_d.p, eng.viol_d.p, age() - 1);
             MMW_HIP(hipGetLastError());
         }
         // until settle() finds a violation or something touches the iterate.  A handle that has had to replay a chunk keeps restarting
