@@ -359,6 +359,15 @@ def main():
         b2b_us = None
     finally:
         os.environ.pop("MMW_BENCH_LANCZOS", None)
+    b2b_first_us = None  # ... and the first-order product (fp16 operands, its whole epilogue) the same way, when the timed region ran on it
+    if first_iters and int(solver.read(_lib.F_SPMM_KIND)[0]) == 3:
+        try:
+            os.environ["MMW_BENCH_FIRST"] = "1"
+            b2b_first_us = solver.bench_spmm(2, 30)
+        except Exception:
+            b2b_first_us = None
+        finally:
+            os.environ.pop("MMW_BENCH_FIRST", None)
     roofline = {"bound": "hbm", "kernel": kinfo["name"] + " of the %s step" % args.expm +
                 ("; first-order epilogue (y = u + (L/2 - mu I)u, the whole exponential) in %d of %d steps" % (first_iters, args.steps) if first_iters else ""),
                 "limiter": kinfo["limiter"],
@@ -366,7 +375,9 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_source": traffic_src if traffic is not None else None,
                 "bytes_per_launch": int(b_spmm), "avg_launch_us": round(spmm_avg_us, 2),
-                "avg_launch_us_back_to_back": None if b2b_us is None else round(b2b_us, 2),
+                "avg_launch_us_back_to_back": None if b2b_us is None else round(b2b_us, 2),  # the Lanczos-epilogue launch (two bf16 planes)
+                "avg_launch_us_back_to_back_first_order": None if b2b_first_us is None else round(b2b_first_us, 2),
+                "frac_back_to_back": None if not (b2b_first_us or b2b_us) else round(b_spmm / ((b2b_first_us or b2b_us) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                 "avg_launch_us_synchronous": round(spmm_sync_us / max(spmm_sync_n, 1), 2), "launches": int(spmm_work),
                 "launches_enqueued": int(spmm_n), "launches_per_step": round(spmm_work / max(args.steps, 1), 2)}
     phases_sync = {k: round(v[0] / max(args.steps, 1), 2) for k, v in kt.items() if v[1]}
