@@ -424,6 +424,11 @@ void k_spmm_mfma(MfmaDev M, int Dpad, size_t plane_bytes, const char* __restrict
             s = wave_sum(s);
             if (lane == 0) E.tr_part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
         }
+        if (stamps && lane == 0) {  // diagnostic runs: the same record as below
+            const unsigned long long te = __builtin_amdgcn_s_memtime();
+            unsigned long long* o = stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wv) * 8;
+            o[0] = t_pro; o[1] = acc_wait; o[2] = acc_issue; o[3] = acc_comp; o[4] = te - tk0; o[5] = (unsigned long long)NC; o[6] = tk0; o[7] = te - tk1;
+        }
         return;
     }
     // ---- epilogue on the accumulator layout: lane = column (lane & 31), register v = row (v & 3) + 8 (v >> 2) + 4 (lane >> 5).
