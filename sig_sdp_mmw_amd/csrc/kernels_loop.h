@@ -5,6 +5,7 @@
 //   averaging (mmw.py:77-78) is folded into the producers of X and Y.
 // Reductions are wavefront shuffles + fixed-order per-block slabs (bitwise reproducible, no atomics).
 #pragma once
+#include <type_traits>
 #include "blocking.h"
 #include "device_utils.h"
 #include "kernels_expm.h"
@@ -114,7 +115,13 @@ __global__ __launch_bounds__(BLOCK) void k_dual_h(PatternDev<T> P, const T* __re
         const int a0 = P.indptr[rowA], a1 = P.indptr[rowA + 1];
         const int b0 = hasB ? a1 : a0, b1 = hasB ? P.indptr[rowB + 1] : a0;  // consecutive rows: B starts where A ends
         const int nmax = max(a1 - a0, b1 - b0);
-        double sA = 0.0, laA = 0.0, ldA = 0.0, sB = 0.0, laB = 0.0, ldB = 0.0;
+        // the |L| row sums of an fp32 handle (they feed the exponential's norm bound, which carries a margin of 1e-3) are formed in fp32:
+        // conversions, double-precision adds and cross-lane steps on these four sums were a fifth of the pass's vector instructions.
+        // The violation sums stay in double: e_accu feeds the softmax, and with a large step size an fp32 sum's rounding (7e-7) was
+        // amplified into 3e-3 of X_half within 24 iterations (test_matrix_core_spmm_steps_aside_when_the_norm_outgrows_the_split).
+        typedef typename std::conditional<sizeof(T) == 4, float, double>::type A;
+        double sA = 0.0, sB = 0.0;
+        A laA = 0, ldA = 0, laB = 0, ldB = 0;
         for (int k = lane; k - lane < nmax; k += WAVE) {
             const bool onA = a0 + k < a1, onB = b0 + k < b1;
             const int ea = onA ? a0 + k : a0, eb = onB ? b0 + k : a0;
@@ -129,14 +136,14 @@ __global__ __launch_bounds__(BLOCK) void k_dual_h(PatternDev<T> P, const T* __re
             if (gb) sB += (double)wb * rbv;
             if (lval) {  // the pass reads these rows anyway: |L| row sums and the diagonal, like k_rowsums
                 if (onA) {
-                    const double v = lscale * (double)va;
+                    const A v = (A)lscale * (A)va;
                     if (ca == rowA) ldA = v;
-                    else laA += fabs(v);
+                    else laA += v < 0 ? -v : v;
                 }
                 if (onB) {
-                    const double v = lscale * (double)vb;
+                    const A v = (A)lscale * (A)vb;
                     if (cb == rowB) ldB = v;
-                    else laB += fabs(v);
+                    else laB += v < 0 ? -v : v;
                 }
             }
         }
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(BLOCK) void k_dual_h(PatternDev<T> P, const T* __re
             laA = wave_sum(laA); ldA = wave_sum(ldA);  // exactly one lane holds a row's diagonal
             laB = wave_sum(laB); ldB = wave_sum(ldB);
             if (tail) {
-                const double la = (lane & 1) ? laB : laA, ld = (lane & 1) ? ldB : ldA;
+                const double la = (double)((lane & 1) ? laB : laA), ld = (double)((lane & 1) ? ldB : ldA);
                 sd += ld;
                 pp = ld + la > pp ? ld + la : pp;
                 pm = la - ld > pm ? la - ld : pm;
