@@ -236,9 +236,18 @@ def test_full_size_first_order_exponential_meets_the_tolerance(eta, nit, expect_
     ip, ix = s.read_i32(_lib.I_L_INDPTR), s.read_i32(_lib.I_L_INDICES)
     K = s.K
     L = scipy.sparse.csr_matrix((s.read(_lib.F_LVAL), ix, ip), shape=(K, K))
-    R = s.read(_lib.F_SKETCH)[:, :24]
-    got = s.read(_lib.F_XHALF)[:, :24]
-    ref = expm_multiply(0.5 * L, R)
-    err = relerr(got, ref)
+    R = s.read(_lib.F_SKETCH)
+    got = s.read(_lib.F_XHALF)
+    ref = expm_multiply(0.5 * L, R[:, :24])
+    err = relerr(got[:, :24], ref)
     assert err < 2e-6, err
+    if expect_first:
+        # what the fused launches of that last iteration left around the exponential, against the oracle's functions on the same state:
+        # X on the pattern (the SDDMM on the planes the product's epilogue wrote, the diagonal from its fixed-point row norms, the
+        # trace from its shares) and the weights (softmax inside the violation pass, normalised by the LOSS pass)
+        from oracle import mmw_oracle as orc
+        pat = orc.Pattern(Z, state)
+        xref = orc.x_on_pattern(pat, expm_multiply(0.5 * L, R))
+        assert relerr(s.read(_lib.F_XVAL), xref) < 1e-4
+        assert relerr(s.read(_lib.F_Y), orc.softmax(s.read(_lib.F_E_ACCU))) < 1e-4
     s.close()
