@@ -754,7 +754,18 @@ __global__ __launch_bounds__(BLOCK) void k_ns_first(int b, const double* __restr
 template <typename T> __global__ __launch_bounds__(1024) void k_max_of(size_t n, const T* __restrict__ a, double* __restrict__ out) {
     __shared__ double sh[16];
     double m = -1e300;
-    for (size_t i = threadIdx.x; i < n; i += 1024) m = (double)a[i] > m ? (double)a[i] : m;
+    // sixteen independent elements per thread and round (one dependent 4-byte load per round took 27 us for 84 k entries: the read-back
+    // of the objective record was 5 % of a 20-step timed region)
+    constexpr int U = 16;
+    const size_t nu = n - n % ((size_t)1024 * U);
+    for (size_t i = threadIdx.x; i < nu; i += (size_t)1024 * U) {
+        T x[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) x[k] = a[i + (size_t)k * 1024];
+#pragma unroll
+        for (int k = 0; k < U; ++k) m = (double)x[k] > m ? (double)x[k] : m;
+    }
+    for (size_t i = nu + threadIdx.x; i < n; i += 1024) m = (double)a[i] > m ? (double)a[i] : m;
     m = block_max(m, sh);
     if (threadIdx.x == 0) out[0] = m;
 }

@@ -823,7 +823,8 @@ template <typename T> struct Solver final : mmw_solver {
             int cap = lagged_ok() ? std::max(8, std::min(32, age())) : std::max(4, std::min(32, age() / 2));
             if (chain_ok && age() >= 4) cap = std::max(cap, std::min(32, room_iterations()));
             if (warm_fresh) cap = 8;
-            const int chunk = std::min(left, cap);
+            int chunk = std::min(left, cap);
+            if (left - chunk == 1) ++chunk;  // no trailing chunk of one iteration: it would run synchronously and break the chain of chunks
             if (plan_seen) m_guess = next_launch_order(chunk);  // before the first readback of a run: the default set by reset()
             first_guess = plan_seen && first_order_ok(chunk);  // (requires that the last plan read back stopped after one step)
             if (first_guess) m_guess = 1;
