@@ -36,9 +36,20 @@ def gather_records(local_records, n_instances, rank, world, dist=None, device=No
         mine = torch.from_numpy(buf)
         if device is not None:
             mine = mine.to(device)
-        parts = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(parts, mine)
-        table = np.concatenate([p.cpu().numpy() for p in parts], axis=0)
+        table = None
+        if device is not None and str(device) != "cpu":
+            # RCCL: one collective into one tensor and ONE copy back (a list of `world` outputs costs `world` device-to-host copies,
+            # ~20 us each -- a tenth of a 20-step timed region on 8 GPUs)
+            try:
+                flat = torch.empty((world * per_rank, RECORD_LEN), dtype=mine.dtype, device=mine.device)
+                dist.all_gather_into_tensor(flat, mine)
+                table = flat.cpu().numpy()
+            except AttributeError:  # an older torch.distributed without the call (the same on every rank)
+                table = None
+        if table is None:
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            table = np.concatenate([p.cpu().numpy() for p in parts], axis=0)
     table = table[~np.isnan(table[:, 0])]
     order = np.argsort(table[:, 0], kind="stable")
     return table[order]
