@@ -26,7 +26,7 @@ constexpr int BLK_ROWS = 64;        // max matrix rows per block
 constexpr int BLK_META_BYTES = MMW_BLK_META;  // LDS bytes for the block's (local index, value) entries
 constexpr int BLK_CHUNK = 16;       // entries per wave step (4 lane groups x 4); rows are padded to this
 constexpr int MF_UNION = 640;       // union columns of a matrix-core block (its LDS holds 16 of them at a time, not all)
-constexpr int MF_KSTEP_PAD = 2;     // a block's 16-row k-steps are padded to a multiple of this in the fragment image (== MF_KPAD)
+constexpr int MF_KSTEP_PAD = 4;     // a block's 16-row k-steps are padded to a multiple of this in the fragment image (== MF_KPAD)
 
 struct HostBlocking {
     bool usable = false;

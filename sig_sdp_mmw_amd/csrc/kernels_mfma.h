@@ -62,7 +62,7 @@ __global__ __launch_bounds__(BLOCK) void k_split_planes(size_t n4, const float4*
 constexpr double SDM_FX = 1099511627776.0;  // 2^40: fixed-point scale of the row totals added with integer atomics (row sums of X, row norms of y)
 constexpr int MF_KROWS = 16;  // union rows per k-step
 constexpr int MF_UNION_ROWS = 640;  // == MF_UNION (blocking.h)
-constexpr int MF_KPAD = 2;    // a block's k-steps are padded to a multiple of this in the fragment image (zero fragments)
+constexpr int MF_KPAD = 4;    // a block's k-steps are padded to a multiple of this in the fragment image (zero fragments)
 struct MfmaDev {             // the matrix-core kernel's own row blocks (blocking.h, build_mfma_blocking)
     int nb;
     const int* desc;         // [nb][8] {first position, rows, 0, 0, 0, union size, 0, 0}
