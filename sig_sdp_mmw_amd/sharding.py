@@ -19,7 +19,21 @@ def instances_of_rank(n_instances, rank, world):
     return list(range(rank, n_instances, world))
 
 
-def gather_records(local_records, n_instances, rank, world, dist=None, device=None):
+_RCCL_BUFFERS = {}  # (rows per rank, world, device) -> page-locked staging and device tensors of the record gather, made on first use
+
+
+def _rccl_buffers(per_rank, world, device):
+    import torch
+    key = (per_rank, world, str(device))
+    if key not in _RCCL_BUFFERS:
+        _RCCL_BUFFERS[key] = (torch.empty((per_rank, RECORD_LEN), dtype=torch.float64).pin_memory(),
+                              torch.empty((per_rank, RECORD_LEN), dtype=torch.float64, device=device),
+                              torch.empty((world * per_rank, RECORD_LEN), dtype=torch.float64, device=device),
+                              torch.empty((world * per_rank, RECORD_LEN), dtype=torch.float64).pin_memory())
+    return _RCCL_BUFFERS[key]
+
+
+def gather_records(local_records, n_instances, rank, world, dist=None, device=None, _force_collective=False):
     """All ranks end up with the (n_instances, RECORD_LEN) table ordered by instance id.
 
     `local_records`: list of RECORD_LEN-float rows produced on this rank.  With world == 1 no
@@ -29,24 +43,26 @@ def gather_records(local_records, n_instances, rank, world, dist=None, device=No
     buf = np.full((per_rank, RECORD_LEN), np.nan, dtype=np.float64)
     for j, rec in enumerate(local_records):
         buf[j] = np.asarray(rec, dtype=np.float64)
-    if world == 1 or dist is None:
+    if (world == 1 and not _force_collective) or dist is None:
         table = buf
     else:
         import torch
-        mine = torch.from_numpy(buf)
-        if device is not None:
-            mine = mine.to(device)
         table = None
         if device is not None and str(device) != "cpu":
             # RCCL: one collective into one tensor and ONE copy back (a list of `world` outputs costs `world` device-to-host copies,
             # ~20 us each -- a tenth of a 20-step timed region on 8 GPUs)
-            try:
-                flat = torch.empty((world * per_rank, RECORD_LEN), dtype=mine.dtype, device=mine.device)
-                dist.all_gather_into_tensor(flat, mine)
-                table = flat.cpu().numpy()
-            except AttributeError:  # an older torch.distributed without the call (the same on every rank)
-                table = None
+            if hasattr(dist, "all_gather_into_tensor"):  # (an older torch.distributed lacks it on every rank alike)
+                host_in, dev_in, dev_out, host_out = _rccl_buffers(per_rank, world, device)
+                host_in.copy_(torch.from_numpy(buf))
+                dev_in.copy_(host_in, non_blocking=True)
+                dist.all_gather_into_tensor(dev_out, dev_in)
+                host_out.copy_(dev_out, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                table = host_out.numpy().copy()
         if table is None:
+            mine = torch.from_numpy(buf)
+            if device is not None:
+                mine = mine.to(device)
             parts = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(parts, mine)
             table = np.concatenate([p.cpu().numpy() for p in parts], axis=0)
