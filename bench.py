@@ -324,10 +324,12 @@ def main():
     solver.iterate(args.warmup, None, seeds[0])
     solver.set_profile(2)
     first0 = float(solver.read(_lib.F_DUAL_INFO)[2])
+    first16_0 = float(solver.read(_lib.F_DUAL_INFO)[3])
     solver.iterate(args.steps, None, seeds[0])
     kt2 = solver.kernel_times()
     solver.set_profile(False)
     first_iters = int(float(solver.read(_lib.F_DUAL_INFO)[2]) - first0)  # steps of this pass whose exponential was ONE first-order product
+    first16_iters = int(float(solver.read(_lib.F_DUAL_INFO)[3]) - first16_0)  # ... with the matrix in one fp16 half
     # the roofline figure is the SpMM of the path the timed region runs (launches of the shipped path, HIP events on the solver's stream)
     spmm_us, spmm_n = kt2["spmm"] if kt2["spmm"][1] else kt["spmm"]
     K, D, nnzL, C = solver.K, solver.D, solver.nnzL, solver.C
@@ -390,7 +392,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
         "config": {"workload": args.workload, "description": desc, "K": K, "Z": Z, "D": D, "nnzL": nnzL, "C": C,
-                   "eta": args.eta, "expm": args.expm, "krylov_order": m_used, "first_order_steps": first_iters, "rng": "device-philox4x32",
+                   "eta": args.eta, "expm": args.expm, "krylov_order": m_used, "first_order_steps": first_iters, "first_order_one_half_matrix_steps": first16_iters, "rng": "device-philox4x32",
                    "instances": n_inst, "instances_per_gpu": M,
                    "parallelism": "instance-sharded x%d" % world + (", %d resident per GPU" % M if M > 1 else "")},
         "instances_per_s": round(n_inst / elapsed, 3),  # solves of `steps` iterations per second, whole job

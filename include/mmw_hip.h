@@ -63,8 +63,9 @@ enum mmw_field {
     MMW_F_SPMM_KIND = 17, /* [2]      SpMM kernel of exp(L/2)R on this handle: 0 generic CSR gather, 1 LDS-staged full tiles, 2 half tiles,
                              3 matrix-core (bf16 hi/lo split); [1] = 1 while the last plan allowed the matrix-core kernel */
     MMW_F_E_MAX = 18,     /* [1]      max_c e_c(X) of the last iteration (the largest entry of MMW_F_E_THIS, reduced on the device) */
-    MMW_F_DUAL_INFO = 19, /* [3]      iterations since mmw_create {whose DUAL phase took the row sums of X from the matrix-core SDDMM instead of a
-                             pass of its own, whose softmax ran inside the violation pass, whose exponential was ONE first-order product} */
+    MMW_F_DUAL_INFO = 19, /* [4]      iterations since mmw_create {whose DUAL phase took the row sums of X from the matrix-core SDDMM instead of a
+                             pass of its own, whose softmax ran inside the violation pass, whose exponential was ONE first-order product,
+                             ... with the matrix in one fp16 half} */
     MMW_F_KERNEL_US = 15  /* [2*9]    per kernel class {total device us, launches} since mmw_set_profile(1):
                              spmm, sddmm, dual, loss, krylov vector ops, sketch, projection, greedy, factor */
 };

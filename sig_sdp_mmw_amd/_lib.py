@@ -234,7 +234,7 @@ class Solver:
             elif which == F_SPMM_KIND:
                 n = 2
             elif which == F_DUAL_INFO:
-                n = 3
+                n = 4
             elif which == F_E_MAX:
                 n = 1
             elif which == F_PHASE_US:

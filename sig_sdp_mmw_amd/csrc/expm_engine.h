@@ -146,7 +146,7 @@ inline int spmm_mfma_launch(hipStream_t st, const MfmaDev& M, int mt, int Dpad, 
     do {                                                                                                                               \
         static bool attr_set = false;                                                                                                  \
         constexpr int gtw = (NW / MS) * NT;                                                                                            \
-        constexpr int lds_bytes = mf_lds_bytes<MT, gtw, KC, NB, mf_planes(MODE)>();                                                                     \
+        constexpr int lds_bytes = mf_lds_bytes<MT, gtw, KC, NB, mf_planes(MODE), mf_apieces(MODE)>();                                                                     \
         if (!attr_set) {                                                                                                               \
             MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_mfma<MODE, MT, NT, NW, MS, KC, NB>),                     \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));                                       \
@@ -182,7 +182,7 @@ inline int spmm_mfma_launch(hipStream_t st, const MfmaDev& M, int mt, int Dpad, 
         if (gt == 4) {
             if (cfg == 1) MMW_MF_LAUNCH(2, 1, 4, 1, 2, 2);
             else if (cfg == 4) MMW_MF_LAUNCH(2, 1, 8, 2, 2, 3);
-            else if (MODE == SPMM_FIRST && cfg != 6) MMW_MF_LAUNCH(2, 1, 8, 2, 4, 2);  // fp16 operands: four k-steps per barrier fit (68 KB): 21.3 -> 20.2 us
+            else if (mf_first(MODE) && cfg != 6) MMW_MF_LAUNCH(2, 1, 8, 2, 4, 2);  // fp16 operands: four k-steps per barrier fit (68 KB): 21.3 -> 20.2 us
             else MMW_MF_LAUNCH(2, 1, 8, 2, 2, 2);
         }
         else if (gt == 8) MMW_MF_LAUNCH(2, 2, 8, 2, 2, 2);
@@ -442,7 +442,9 @@ template <typename T> struct ExpmEngine {
     // leaves in partial_o2 (k_sddmm_mfma's verification workgroup).  No scalar launch, no combination: y leaves the product's
     // epilogue as the SDDMM's planes (and as fp32 in `out` when given), its row norms as fixed-point totals in `dfx` (zero at launch)
     // and the trace as one share per workgroup in `tr_part` (*ntr entries).  A uniform factor e^mu is dropped: X = y y^T / tr.
-    int apply_first(T* out, double ascale, int m_launch, bool plan_made, unsigned short* y_planes, long long* dfx, double* tr_part, int* ntr) {
+    // afrag16 != nullptr: the matrix as ONE fp16 half in an image of its own (SPMM_FIRST16; the caller's LOSS pass wrote it)
+    int apply_first(T* out, double ascale, int m_launch, bool plan_made, unsigned short* y_planes, long long* dfx, double* tr_part, int* ntr,
+                    const unsigned short* afrag16 = nullptr) {
         if constexpr (std::is_same<T, float>::value) {
             if (!plan_made) MMW_TRY(make_plan(ascale, m_launch));
             MMW_TRY(ensure_planes());
@@ -456,8 +458,14 @@ template <typename T> struct ExpmEngine {
             MfEpi E;
             E.y_planes = y_planes; E.dfx = dfx; E.tr_part = tr_part;
             MMW_TRY(kbegin(KT_SPMM));
-            MMW_TRY((spmm_mfma_launch<SPMM_FIRST>(st, mf, mf_mt, lay.Dpad, bs * sizeof(unsigned short), reinterpret_cast<const char*>(planes_of(0)), U.p, out,
-                                                  ascale / (double)MF_F16_SCALE, 0.0, partial.p, partial_o2.p, plan_d.p, 1, viol_d.p, E, ntr)));
+            if (afrag16) {
+                MfmaDev m16 = mf;
+                m16.afrag = reinterpret_cast<const unsigned*>(afrag16);
+                MMW_TRY((spmm_mfma_launch<SPMM_FIRST16>(st, m16, mf_mt, lay.Dpad, bs * sizeof(unsigned short), reinterpret_cast<const char*>(planes_of(0)), U.p, out,
+                                                        ascale / (double)MF_F16_SCALE, 0.0, partial.p, partial_o2.p, plan_d.p, 1, viol_d.p, E, ntr)));
+            } else
+                MMW_TRY((spmm_mfma_launch<SPMM_FIRST>(st, mf, mf_mt, lay.Dpad, bs * sizeof(unsigned short), reinterpret_cast<const char*>(planes_of(0)), U.p, out,
+                                                      ascale / (double)MF_F16_SCALE, 0.0, partial.p, partial_o2.p, plan_d.p, 1, viol_d.p, E, ntr)));
             MMW_TRY(kend());
             planes_ready[0] = false;
             planes0_f16 = false;

@@ -30,6 +30,7 @@ struct ExpmPlan {      // written by k_plan, read by every expm kernel
     int m_eff;         // steps the last application actually used (written by the combination)
     int mfma_ok;       // 1: the two-half bf16 split of the matrix-core SpMM (kernels_mfma.h) keeps the product within tol
     int f16_ok;        // 1: so does the first-order product's single fp16 plane of u: 2^-12 max_i sum_j |a_ij| <= tol
+    int f16a_ok;       // 1: ... and with the matrix in ONE fp16 half as well (SPMM_FIRST16): 2 * 2^-12 max_i sum_j |a_ij| <= tol
     double absn;       // max_i sum_j |a_ij| of the scaled matrix (the bound behind mfma_ok)
     // Lagged planning (the loop's optimistic chunks): the row sums of the matrix are made one iteration late, inside the DUAL
     // pass that reads the same rows, and the bounds for the matrix that is multiplied are extrapolated from the last two
@@ -61,7 +62,7 @@ __device__ __forceinline__ int plan_steps(const ExpmPlan* p, int upto) {
     return m;
 }
 
-enum { SPMM_PLAIN = 0, SPMM_LANCZOS = 1, SPMM_TAYLOR = 2, SPMM_AXPBY = 3, SPMM_FIRST = 4 /* kernels_mfma.h only */ };
+enum { SPMM_PLAIN = 0, SPMM_LANCZOS = 1, SPMM_TAYLOR = 2, SPMM_AXPBY = 3, SPMM_FIRST = 4, SPMM_FIRST16 = 5 /* the last two: kernels_mfma.h only */ };
 
 // Out = ascale * A * U (+ mode-specific fused epilogue).  One wavefront per matrix row, grid-stride.
 //   SPMM_LANCZOS: also partial[block][col] = sum_rows U[row,col] * Out[row,col]   (alpha numerators)
@@ -1414,6 +1415,7 @@ __device__ __forceinline__ void plan_body(int K, int method, int max_order, doub
         p.absn = pp > pm ? pp : pm;
         p.mfma_ok = 2.3e-5 * p.absn <= tol ? 1 : 0;
         p.f16_ok = 2.4415e-4 * p.absn <= tol && p.absn < 0.03 ? 1 : 0;  // 2^-12; and the entries times 2^20 stay inside fp16's range
+        p.f16a_ok = p.f16_ok && 2.0 * 2.4415e-4 * p.absn <= tol ? 1 : 0;
         // the a-posteriori stop needs the shifted recurrence of the half-tile SpMM, a single substep and a geometric tail
         p.apost = apost && method == 0 && nsub == 1 && !p.overflow && r < 0.5;
         for (int i = 0; i < MAX_ORDER + 2; ++i) p.conv[i] = 0u;  // identity of the maximum; a step's entry is read only after its k_lz_scalars ran

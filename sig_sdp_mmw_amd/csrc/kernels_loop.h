@@ -355,7 +355,8 @@ __global__ __launch_bounds__(BLOCK) void k_loss(PatternDev<T> P, const int* __re
                                                 unsigned* __restrict__ afrag = nullptr, T* __restrict__ Ynorm = nullptr,
                                                 T* __restrict__ yavg = nullptr, int accumulate = 0, PlanArgs pa = PlanArgs{},
                                                 long long* __restrict__ rs_zero = nullptr /* fixed-point totals the coming product / SDDMM add to */,
-                                                int rs_zero_n = 0, int afrag_f16 = 0 /* 1: the image feeds the first-order product (split_f16_scaled) */) {
+                                                int rs_zero_n = 0, int afrag_f16 = 0 /* 1: the image feeds the first-order product (split_f16_scaled) */,
+                                                unsigned short* __restrict__ afrag16 = nullptr /* ... as ONE fp16 half, in an image of its own (SPMM_FIRST16) */) {
     // Ynorm != nullptr: Y and wH hold the unnormalised exponentials of the fused DUAL pass (k_dual_h, mref form) and scal[3]
     // their total; this pass divides where it uses them and writes the normalised Y (and its running sum) on the side.
     if ((int)blockIdx.x < sk.nblocks) {  // leading workgroups draw this iteration's sketch (same shape as k_sketch_rng: same bits)
@@ -403,7 +404,10 @@ __global__ __launch_bounds__(BLOCK) void k_loss(PatternDev<T> P, const int* __re
         const T nv = (T)((double)lval[e] - eta * add);
         lval[e] = nv;
         if (bpos) lval_blk[bpos[e]] = nv;  // the same value in the LDS-staged kernel's traversal order
-        if (fpos) afrag[fpos[e]] = afrag_f16 ? split_f16_scaled((float)nv) : split_bf16((float)nv);  // and as two 16-bit halves in the matrix-core kernel's fragment order
+        if (fpos) {  // and in the matrix-core kernel's fragment order: two 16-bit halves, or (the first-order product early in a run) one fp16 half
+            if (afrag16) afrag16[mf_pos16(fpos[e])] = f16_rn((float)nv * MF_F16_SCALE);
+            else afrag[fpos[e]] = afrag_f16 ? split_f16_scaled((float)nv) : split_bf16((float)nv);
+        }
         if (xavg) xavg[e] += xval[e];  // the previous iteration's X joins the running sum here (same index space, one pass fewer)
     }
 }

@@ -90,10 +90,13 @@ struct MfEpi {
 // a chunk = KC k-steps: per k-step the B image (2 planes x 16 rows x the group's columns), then the A fragments of all KC steps
 // GT = column tiles per workgroup
 // PL = planes of the B operand: 2 (bf16 hi / lo) or 1 (one fp16 plane: the first-order product, below)
-template <int MT, int GT, int KC, int PL = 2> constexpr int mf_chunk_bytes() { return KC * (1024 * PL * GT + 2048 * MT); }
+// AP = 1-KiB pieces of the A operand per k-step and row tile: 2 (two 16-bit halves per entry) or 1 (one fp16 half: SPMM_FIRST16)
+template <int MT, int GT, int KC, int PL = 2, int AP = 2> constexpr int mf_chunk_bytes() { return KC * (1024 * PL * GT + 1024 * AP * MT); }
 // NB = chunks resident in LDS (one being multiplied, NB - 1 in flight)
-template <int MT, int GT, int KC, int NB, int PL = 2> constexpr int mf_lds_bytes() { return MF_UNION_ROWS * 4 + 64 * 4 + NB * mf_chunk_bytes<MT, GT, KC, PL>(); }
-constexpr int mf_planes(int mode) { return mode == SPMM_FIRST ? 1 : 2; }
+template <int MT, int GT, int KC, int NB, int PL = 2, int AP = 2> constexpr int mf_lds_bytes() { return MF_UNION_ROWS * 4 + 64 * 4 + NB * mf_chunk_bytes<MT, GT, KC, PL, AP>(); }
+constexpr bool mf_first(int mode) { return mode == SPMM_FIRST || mode == SPMM_FIRST16; }
+constexpr int mf_planes(int mode) { return mf_first(mode) ? 1 : 2; }
+constexpr int mf_apieces(int mode) { return mode == SPMM_FIRST16 ? 1 : 2; }
 typedef _Float16 mf_h8 __attribute__((ext_vector_type(8)));
 // The first-order product runs on fp16 operands: its result o = A'u enters y = u + o at q = ||A'u|| / ||u|| ~ 1e-4, so ONE fp16 plane of u
 // (11 significant bits: ||d o|| <= 2^-12 || |A| ||_2 ||u||, ExpmPlan::f16_ok) replaces the two bf16 halves -- half the gather, two products
@@ -108,6 +111,12 @@ __device__ __forceinline__ unsigned split_f16_scaled(float x) {
     const unsigned short hi = f16_rn(xs);
     const unsigned short lo = f16_rn(xs - f16_f32(hi));
     return ((unsigned)hi << 16) | (unsigned)lo;
+}
+// position of an entry in the one-half image (SPMM_FIRST16) from its position `w` in the two-halves image (blocking.h, fpos): the same
+// (k-step, row tile, lane), the lane's 8 entries contiguous
+__device__ __forceinline__ size_t mf_pos16(int w) {
+    const int j = (w & 3) + 4 * ((w >> 8) & 1), lane = (w >> 2) & 63;
+    return ((size_t)(w >> 9) * 64 + lane) * 8 + j;
 }
 // one fp16 plane of an fp32 block (the first-order product's B operand, when the block's producer did not write it)
 __global__ __launch_bounds__(BLOCK) void k_plane_f16(size_t n4, const float4* __restrict__ src, uint2* __restrict__ dst) {
@@ -148,9 +157,12 @@ __global__ __launch_bounds__(NW * 64)
 void k_spmm_mfma(MfmaDev M, int Dpad, size_t plane_bytes, const char* __restrict__ Upl, const float* __restrict__ U,
                  float* __restrict__ Out, double ascale_d, double shift_d, double* __restrict__ partial, double* __restrict__ partial_o2,
                  const ExpmPlan* __restrict__ plan, int step, int* __restrict__ viol, unsigned long long* __restrict__ stamps, MfEpi E) {
-    static_assert(MODE == SPMM_PLAIN || MODE == SPMM_LANCZOS || MODE == SPMM_AXPBY || MODE == SPMM_FIRST, "the matrix-core SpMM has the plain, the Lanczos, the AXPBY and the first-order epilogue");
+    static_assert(MODE == SPMM_PLAIN || MODE == SPMM_LANCZOS || MODE == SPMM_AXPBY || mf_first(MODE), "the matrix-core SpMM has the plain, the Lanczos, the AXPBY and the first-order epilogue");
     static_assert(MF_KPAD % KC == 0, "the fragment image pads a block's k-steps to whole chunks");
-    constexpr bool F16 = MODE == SPMM_FIRST;  // one fp16 plane of u, fp16 hi / lo of the matrix (see MF_F16_SCALE)
+    constexpr bool F16 = mf_first(MODE);      // one fp16 plane of u, fp16 hi / lo of the matrix (see MF_F16_SCALE)
+    constexpr bool A16 = MODE == SPMM_FIRST16;  // ... the matrix in ONE fp16 half while 2 * 2^-12 absn <= tol (ExpmPlan::f16a_ok): an image of its own,
+                                                // lane l of a (k-step, row tile) holds its 8 entries as 16 contiguous bytes -- half the A bytes, one product
+    constexpr int AP = mf_apieces(MODE), AB = 1024 * AP;  // bytes of A per k-step and row tile
     // diagnostic runs only (stamps != nullptr): shader-clock sums per wave {prologue, wait + barrier, DMA issue, products, epilogue, steps}
     unsigned long long tk0 = 0, tk1 = 0, acc_wait = 0, acc_issue = 0, acc_comp = 0, t_pro = 0;
     if (stamps) tk0 = __builtin_amdgcn_s_memtime();
@@ -163,11 +175,11 @@ void k_spmm_mfma(MfmaDev M, int Dpad, size_t plane_bytes, const char* __restrict
             if (step > plan_steps(plan, step - 1)) return;
             shifted = plan->apost != 0 && partial_o2 != nullptr;
             if (shifted) shift_d = plan->mu;
-        } else if (MODE == SPMM_FIRST) {
+        } else if (F16) {
             shift_d = plan->mu;
         } else if (step > plan->m) return;
         // launched without a plan readback on a matrix whose norm has outgrown the two-half split: the chunk is replayed on the fp32 kernel
-        if (!(F16 ? plan->f16_ok : plan->mfma_ok) && viol && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *viol = 1;
+        if (!(A16 ? plan->f16a_ok : (F16 ? plan->f16_ok : plan->mfma_ok)) && viol && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *viol = 1;
     }
     const float ascale = (float)ascale_d, shift = (float)shift_d;
     static_assert(NW % MS == 0 && MT % MS == 0, "row tiles and waves split evenly");
@@ -175,7 +187,7 @@ void k_spmm_mfma(MfmaDev M, int Dpad, size_t plane_bytes, const char* __restrict
     constexpr int MTW = MT / MS;   // row tiles per wave
     constexpr int GT = NWN * NT;   // column tiles (32 columns, 64 bytes per plane row) per workgroup
     constexpr int PL = mf_planes(MODE);
-    constexpr int CHUNK = mf_chunk_bytes<MT, GT, KC, PL>();
+    constexpr int CHUNK = mf_chunk_bytes<MT, GT, KC, PL, AP>();
     constexpr int B1 = 1024 * PL * GT;  // B image of one k-step (at the group's full width)
     constexpr int A_OFF = KC * B1;     // the A fragments sit behind the B images of the chunk
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -210,14 +222,14 @@ void k_spmm_mfma(MfmaDev M, int Dpad, size_t plane_bytes, const char* __restrict
     // runs of the B image (64 slots of 16 bytes: slot -> plane, row, 16-byte piece of the row) and pieces [2 ng, 2 ng + 2 MT) the
     // A fragment halves.  Both kinds share one address form, src = base + un_l[16 KC c + row] * mul + c * step (B: mul = row
     // pitch, step = 0; A: mul = 0), so the issue loop has no branch but the piece count.
-    constexpr int NJ = (KC * (PL * GT + 2 * MT) + NW - 1) / NW;
-    const int nB1 = PL * ng, nP1 = nB1 + 2 * MT, nI = KC * nP1;
+    constexpr int NJ = (KC * (PL * GT + AP * MT) + NW - 1) / NW;
+    const int nB1 = PL * ng, nP1 = nB1 + AP * MT, nI = KC * nP1;
     const int cw = wv < nI ? (nI - wv + NW - 1) / NW : 0;  // pieces of this wave per chunk
     const char* pbase[NJ];
     unsigned pmul[NJ];
     int prow[NJ], pdst[NJ];
     const unsigned pitch = (unsigned)Dpad * 2u;
-    const char* afr = reinterpret_cast<const char*>(M.afrag) + (size_t)kb * (2048 * MT);
+    const char* afr = reinterpret_cast<const char*>(M.afrag) + (size_t)kb * (AB * MT);
     const float rP1 = 1.0f / (float)nP1, rspr = 1.0f / (float)spr;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -238,14 +250,14 @@ void k_spmm_mfma(MfmaDev M, int Dpad, size_t plane_bytes, const char* __restrict
             prow[j] = kk * MF_KROWS + r;
             pdst[j] = kk * B1 + i1 * 1024;
         } else if (i < nI) {
-            pbase[j] = afr + (kk * (2048 * MT) + (i1 - nB1) * 1024 + lane * 16);
-            pdst[j] = A_OFF + kk * (2048 * MT) + (i1 - nB1) * 1024;
+            pbase[j] = afr + (kk * (AB * MT) + (i1 - nB1) * 1024 + lane * 16);
+            pdst[j] = A_OFF + kk * (AB * MT) + (i1 - nB1) * 1024;
         }
         pdst[j] = __builtin_amdgcn_readfirstlane(pdst[j]);
     }
     auto issue = [&](int c) {  // chunk c -> buffer c % NB
         const unsigned dst_l = bufs_l + (unsigned)((c % NB) * CHUNK);
-        const unsigned astep = (unsigned)c * (unsigned)(KC * 2048 * MT);
+        const unsigned astep = (unsigned)c * (unsigned)(KC * AB * MT);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             if (j < cw) {  // wave-uniform
@@ -299,8 +311,13 @@ void k_spmm_mfma(MfmaDev M, int Dpad, size_t plane_bytes, const char* __restrict
             mf_s8 ahi[MTW], alo[MTW];
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {  // the two halves of the A fragment: word = hi << 16 | lo per k
-                const char* af = cb + A_OFF + (kk * MT + wm * MTW + m) * 2048 + lane * 16;
+                const char* af = cb + A_OFF + (kk * MT + wm * MTW + m) * AB + lane * 16;
                 const uint4 a0 = *reinterpret_cast<const uint4*>(af);
+                if constexpr (A16) {  // one half only: the lane's 8 entries as they stand
+                    ahi[m] = __builtin_bit_cast(mf_s8, a0);
+                    alo[m] = ahi[m];
+                    continue;
+                }
                 const uint4 a1 = *reinterpret_cast<const uint4*>(af + 1024);
                 const unsigned w[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
                 unsigned h[4], l[4];
@@ -323,7 +340,7 @@ void k_spmm_mfma(MfmaDev M, int Dpad, size_t plane_bytes, const char* __restrict
                     const mf_s8 bh = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
 #pragma unroll
                     for (int m = 0; m < MTW; ++m) {
-                        acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mf_h8, alo[m]), __builtin_bit_cast(mf_h8, bh), acc[m][i], 0, 0, 0);
+                        if constexpr (!A16) acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mf_h8, alo[m]), __builtin_bit_cast(mf_h8, bh), acc[m][i], 0, 0, 0);
                         acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mf_h8, ahi[m]), __builtin_bit_cast(mf_h8, bh), acc[m][i], 0, 0, 0);
                     }
                 } else {
@@ -343,7 +360,7 @@ void k_spmm_mfma(MfmaDev M, int Dpad, size_t plane_bytes, const char* __restrict
         if (stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_comp += t - tk1; tk1 = t; }
     }
 
-    if constexpr (MODE == SPMM_FIRST) {
+    if constexpr (F16) {
         // ---- first-order epilogue: y = u + o, o = ascale A u - mu u.  Leaves y (planes, optionally fp32), the column sums of o^2 (the
         // bound's q), the row sums of y^2 and the workgroup's share of the trace.
         const int h2 = lane >> 5, cl = lane & 31;

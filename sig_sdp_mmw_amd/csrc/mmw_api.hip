@@ -89,6 +89,10 @@ template <typename T> struct Solver final : mmw_solver {
                              // y = exp(L/2)R from the first-order product (kernels_mfma.h).  Zeroed by every LOSS pass.
     DevBuf<double> tr1_part; // trace shares of the first-order product's workgroups (zero where none works)
     const bool first_enabled = getenv("MMW_NO_FIRST_ORDER") == nullptr;
+    const bool first_a16_enabled = getenv("MMW_NO_FIRST_A16") == nullptr;
+    DevBuf<unsigned short> afrag16;  // the matrix as ONE fp16 half, for the first-order product while 2 * 2^-12 absn <= tol (holes zero; an image of its own)
+    bool first_a16_guess = false;    // the chunk being enqueued takes that form
+    long long n_first16_iters = 0;
     bool first_guess = false;  // the chunk being enqueued takes the first-order exponential (first_order_ok at its start)
     int age0 = 0;              // iterations L_accu had accumulated when this run started (a warm restart continues it): the matrix's norm and
                                // every estimate derived from it grow with age() = age0 + iter, not with the run's own counter
@@ -405,6 +409,8 @@ template <typename T> struct Solver final : mmw_solver {
             afrag_n = (size_t)HB.kbase[HB.nbm()] * HB.mfma_mt * 512;
             MMW_TRY(afrag.alloc(afrag_n));
             MMW_HIP(hipMemsetAsync(afrag.p, 0, afrag_n * sizeof(unsigned), st));
+            MMW_TRY(afrag16.alloc(afrag_n));
+            MMW_HIP(hipMemsetAsync(afrag16.p, 0, afrag_n * sizeof(unsigned short), st));
             eng.use_mfma = true;
             eng.mf.nb = HB.nbm();
             eng.mf.desc = b_mdesc.p;
@@ -708,6 +714,7 @@ template <typename T> struct Solver final : mmw_solver {
         MMW_HIP(hipMemsetAsync(lval.p, 0, nnz * sizeof(T), st));
         if (lval_blk.p) MMW_HIP(hipMemsetAsync(lval_blk.p, 0, (size_t)HB.nent * sizeof(T), st));
         if (afrag.p) MMW_HIP(hipMemsetAsync(afrag.p, 0, afrag_n * sizeof(unsigned), st));
+        if (afrag16.p) MMW_HIP(hipMemsetAsync(afrag16.p, 0, afrag_n * sizeof(unsigned short), st));
         eng.last_mfma_ok = true;
         lblk_stale = false;
         MMW_HIP(hipMemsetAsync(xval.p, 0, nnz * sizeof(T), st));
@@ -828,6 +835,8 @@ template <typename T> struct Solver final : mmw_solver {
             if (plan_seen) m_guess = next_launch_order(chunk);  // before the first readback of a run: the default set by reset()
             first_guess = plan_seen && first_order_ok(chunk);  // (requires that the last plan read back stopped after one step)
             if (first_guess) m_guess = 1;
+            first_a16_guess = first_guess && first_a16_enabled && afrag16.p != nullptr &&
+                              2.0 * 2.4415e-4 * eng.last.absn * growth_ratio(chunk) <= eng.last.tol;  // ExpmPlan::f16a_ok over the chunk
             if (warm_fresh) {  // the plan at hand belongs to the previous probe's slot count: one spare step, no first-order form
                 m_guess = std::min(eng.max_order, std::max(2, eng.last.m_eff + 1));
                 first_guess = false;
@@ -1019,7 +1028,8 @@ template <typename T> struct Solver final : mmw_solver {
                                (const int*)(eng.use_blk && !mf_it ? b_bpos.p : nullptr), lval_blk.p,
                                (const T*)(xavg_deferred ? xval.p : nullptr), xavg_deferred ? xavg.p : (T*)nullptr, skl, Dpad,
                                (const int*)(eng.use_mfma ? b_fpos.p : nullptr), afrag.p, fused_dual ? Y.p : (T*)nullptr, yavg.p, acc, pl_loss,
-                               rs_zeroed ? rsfx.p : (long long*)nullptr, rs_zeroed ? (first_it ? 2 * K : K) : 0, first_it ? 1 : 0);
+                               rs_zeroed ? rsfx.p : (long long*)nullptr, rs_zeroed ? (first_it ? 2 * K : K) : 0, first_it ? 1 : 0,
+                               first_it && first_a16_guess ? afrag16.p : (unsigned short*)nullptr);
             xavg_deferred = false;
             MMW_TRY(kt.end());
             MMW_TRY(record(2));
@@ -1063,8 +1073,10 @@ template <typename T> struct Solver final : mmw_solver {
                     MMW_TRY(tr1_part.alloc(need));
                     MMW_HIP(hipMemsetAsync(tr1_part.p, 0, need * sizeof(double), st));
                 }
-                MMW_TRY(eng.apply_first(eng.planes_only ? (T*)nullptr : Xh.p, 0.5, m_launch, lagged_it, xh_planes.p, rsfx.p + K, tr1_part.p, &ntr1));
+                MMW_TRY(eng.apply_first(eng.planes_only ? (T*)nullptr : Xh.p, 0.5, m_launch, lagged_it, xh_planes.p, rsfx.p + K, tr1_part.p, &ntr1,
+                                        first_a16_guess ? afrag16.p : (const unsigned short*)nullptr));
                 ++n_first_iters;
+                if (first_a16_guess) ++n_first16_iters;
             } else
                 MMW_TRY(eng.apply(Xh.p, 0.5, m_launch, lagged_it));
             MMW_TRY(kt.begin(KT_SDDMM));
@@ -1256,8 +1268,8 @@ template <typename T> struct Solver final : mmw_solver {
                 return MMW_OK;
             }
             case MMW_F_DUAL_INFO: {
-                if (n != 3) return fail(MMW_ERR_ARG, "dual info has 3 entries");
-                out[0] = (double)n_rs_iters; out[1] = (double)n_fused_iters; out[2] = (double)n_first_iters;
+                if (n != 4) return fail(MMW_ERR_ARG, "dual info has 4 entries");
+                out[0] = (double)n_rs_iters; out[1] = (double)n_fused_iters; out[2] = (double)n_first_iters; out[3] = (double)n_first16_iters;
                 return MMW_OK;
             }
             case MMW_F_FACTOR: return extras.read_factor(out, n);

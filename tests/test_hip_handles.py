@@ -363,3 +363,26 @@ def test_first_order_exponential_is_replayed_when_its_bound_misses_the_tolerance
     for f, x in zip(FIELDS, got):
         assert relerr(x, b.read(f)) < 2e-5, f
     b.close()
+
+
+def test_first_order_product_with_the_matrix_in_one_fp16_half(monkeypatch):
+    """Early in a run (2 * 2^-12 max_i sum_j |a_ij| <= tol, ExpmPlan::f16a_ok) the first-order product reads the matrix as ONE fp16 half from
+    an image of its own: half the bytes of the matrix, one product per tile and k-step.  A small step size keeps the whole run inside
+    that gate; the run agrees with the two-halves form to the tolerance both meet."""
+    state = journal_graph(16, 0.02, seed=4)
+    Z, nit, eta = 24, 48, 0.004
+    a = _lib.Solver(Z, state, nit, eta, dtype=_lib.F32)
+    a.iterate(nit, None, seed=9)
+    got = [a.read(f) for f in FIELDS]
+    info = a.read(_lib.F_DUAL_INFO)
+    assert info[3] >= nit // 3 and info[3] <= info[2], info
+    assert a.read(_lib.F_BLOCKING)[3] == 0
+    a.close()
+    monkeypatch.setenv("MMW_NO_FIRST_A16", "1")
+    b = _lib.Solver(Z, state, nit, eta, dtype=_lib.F32)
+    b.iterate(nit, None, seed=9)
+    ib = b.read(_lib.F_DUAL_INFO)
+    assert ib[3] == 0 and ib[2] > 0, ib
+    for f, x in zip(FIELDS, got):
+        assert relerr(x, b.read(f)) < 2e-5, f
+    b.close()
