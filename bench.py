@@ -347,6 +347,8 @@ def main():
                 rec = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 if rec.get("workload") == args.workload and dtype_name == "f32" and args.expm == "lanczos":
                     traffic = rec.get("traffic_bytes_per_launch_first_order") if first_iters else None
+                    if first16_iters * 2 >= args.steps and rec.get("traffic_bytes_per_launch_first_order_one_half"):
+                        traffic = rec["traffic_bytes_per_launch_first_order_one_half"]
                     if traffic is None:
                         traffic = rec["traffic_bytes_per_launch"]
                     traffic_src = "profiles/" + fn
