@@ -4,6 +4,7 @@
 R=${1:-rXX}
 cd $GRAFT_REPO_ROOT
 python bench.py > gpurun_out/${R}_g_bench_journal-1pct_plain.json 2> gpurun_out/${R}_g.err
+python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${R}_l_bench_journal-1pct_steps20.json 2> gpurun_out/${R}_l.err   # the driver's command
 bash tools/profile_bench.sh ${R}_b_bench_journal-1pct --cpu-iters 0 --no-coloring > gpurun_out/${R}_b.log 2>&1
 bash tools/profile_bench.sh ${R}_a_coloring_journal-1pct --cpu-iters 0 --steps 20 --warmup 5 > gpurun_out/${R}_a.log 2>&1
 bash tools/pmc_traffic.sh ${R}_c > gpurun_out/${R}_c.log 2>&1
