@@ -164,9 +164,15 @@ def coloring_block(state, dtype_name, nit, eta, warm, geometry=None, speculate=F
         score = {"bler_mean": float(np.mean(bler)), "bler_max": float(np.max(bler)), "sinr_min": float(np.min(sinr)),
                  "scorer_ms": round((time.perf_counter() - s0) * 1e3, 2)}
         env.close()
-    return {"wall_s": round(wall, 4), "Z": int(Z), "rem": int(rem), "probes": int(per.shape[0]), "nit_per_probe": int(nit), "score": score,
+    its = [int(x) for x in lg["mmw_iters"][:, 5]] if "mmw_iters" in lg and not speculate else None
+    return {"wall_s": round(wall, 4), "Z": int(Z), "rem": int(rem), "probes": int(per.shape[0]),
+            "nit_per_probe": its if its is not None else int(nit),  # iterations every probe actually ran
+            "semantics": ("warm-started probes (opt-in, NOT the reference's search): later probes continue from the previous probe's iterate and run "
+                          "ceil(nit/3) iterations" if warm else
+                          "reference: every probe restarts from Y = 1/C, X = I and runs nit iterations (mmw.py:62-68)"),
+            "score": score,
             "warm_start": bool(warm), "mids": [int(x) for x in per[:, 5]], "rems": [int(x) for x in per[:, 7]],
-            "iterations": [int(x) for x in lg["mmw_iters"][:, 5]] if "mmw_iters" in lg and not speculate else None,
+            "iterations": its,
             "speculation": ({"probes_solved_ahead_and_dropped": int(bs.LOGGED_NP_DATA["bs_speculation"][0, 4])}
                             if speculate and "bs_speculation" in bs.LOGGED_NP_DATA else None),
             "per_probe_ms": dict({"solve": [ms(x) for x in per[:, 8]], "rounding": [ms(x) for x in per[:, 9]]},
@@ -180,7 +186,9 @@ def main():
     ap.add_argument("--steps", type=int, default=150)   # nit = 150 is the reference's production setting
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="journal-1pct", choices=sorted(WORKLOADS))
-    ap.add_argument("--instances-per-gpu", type=int, default=1, help="resident handles per rank, iterations enqueued round-robin (configs[3]: 8)")
+    ap.add_argument("--instances-per-gpu", type=int, default=None,
+                    help="resident handles per rank (default 1; 8 for `--workload er-5pct-2k --gpus 8`, BASELINE configs[3])")
+    ap.add_argument("--repeats", type=int, default=7, help="timed regions (each: reset, W untimed warm-up steps, K timed steps); value = median")
     ap.add_argument("--instance-threads", action="store_true", help="(default with --instances-per-gpu M > 1) one host thread per instance")
     ap.add_argument("--no-instance-threads", action="store_true", help="with --instances-per-gpu M: one host thread enqueues all instances round-robin")
     ap.add_argument("--expm", default="lanczos", choices=["lanczos", "taylor"])
@@ -190,7 +198,9 @@ def main():
     ap.add_argument("--no-coloring", action="store_true", help="skip the binary search to a converged colouring")
     ap.add_argument("--coloring-nit", type=int, default=150)
     ap.add_argument("--coloring-speculate", action="store_true", help="two probes in flight on two handles (binary_search.speculate; opt-in)")
-    ap.add_argument("--coloring-cold", action="store_true", help="every probe restarts from Y = 1/C, X = I like the reference (mmw.py:62-68)")
+    ap.add_argument("--coloring-cold", action="store_true", help="(kept for compatibility: the cold, reference-semantics search is always reported as `coloring`)")
+    ap.add_argument("--no-coloring-warm", action="store_true", help="skip the additional warm-started search (`coloring_warm_start`)")
+    ap.add_argument("--no-fp32-operands", action="store_true", help="skip the second handle with strictly-fp32 operands (`value_fp32_operands`)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --single-device rehearses N>1 on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="every rank uses GPU 0 (rehearsal only)")
     args = ap.parse_args()
@@ -207,6 +217,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if args.instances_per_gpu is None:
+        args.instances_per_gpu = 8 if (args.workload == "er-5pct-2k" and args.gpus == 8) else 1  # configs[3]: 64 graphs, 8 per GPU
     M = max(1, args.instances_per_gpu)
 
     import torch
@@ -280,33 +292,57 @@ def main():
             for s in solvers:
                 s.sync()
 
-    # ---- warmup, then the timed region: exactly `steps` iterations (of every instance)
-    run_steps(args.warmup)
-    for s in solvers:
-        s.read(_lib.F_E_MAX)  # the read-back of the timed region's objective record, once untimed (first launch of its kernel)
-    # ... and the gather of the records, once untimed: the first collective of a shape sets its transport up
-    # (three times: on one rank the first RCCL gather took 2.9 ms, the second 0.28 ms, later ones 0.06-0.09 ms; the barrier 17 / 0.1 / 0.04 ms)
-    for _ in range(3):
-        sharding.gather_records([[i, Zi, 0.0, 0.0, 0, 0.0] for i, Zi in zip(mine, Zs)], n_inst, rank, world, dist=dist, device=coll_dev if dist is not None else None)
+    # ---- the timed regions.  Each one: back to the initial point, `warmup` untimed steps, then exactly `steps` iterations of every
+    # instance between two barriers (+ device synchronisation), closed by the gather of the per-instance objective records.  The region is
+    # short (2 ms at the driver's 20 steps), so it is repeated and the line reports the median with its spread.
+    def gather(recs):
+        return sharding.gather_records(recs, n_inst, rank, world, dist=dist, device=coll_dev if dist is not None else None)
+
+    def timed_region(group, seeds_g):
+        """-> (seconds of the whole region, seconds of its tail = records + gather + barrier, table)"""
+        for s in group:
+            s.reset(nit)
+        run_group(group, seeds_g, args.warmup)
+        for s in group:
+            s.read(_lib.F_E_MAX)  # the read-back of the objective record, once untimed (also waits for the warm-up)
         barrier()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    # per-instance objective record, gathered to every rank (RCCL all_gather over xGMI, 48 B per instance)
-    wall_us = (time.perf_counter() - t0) * 1e6
-    _tA = time.perf_counter()
-    recs = [[i, Zi, 0.0, float(s.read(_lib.F_E_MAX)[0]), args.steps, wall_us] for i, Zi, s in zip(mine, Zs, solvers)]  # max_c e_c(X), reduced on the device
-    table = sharding.gather_records(recs, n_inst, rank, world, dist=dist, device=coll_dev if dist is not None else None)
-    assert table.shape[0] == n_inst, table.shape
-    _tB = time.perf_counter()
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
+        t0 = time.perf_counter()
+        run_group(group, seeds_g, args.steps)
+        tA = time.perf_counter()
+        wall_us = (tA - t0) * 1e6
+        # per-instance objective record, gathered to every rank (RCCL all_gather over xGMI, 48 B per instance)
+        recs = [[i, Zi, 0.0, float(s.read(_lib.F_E_MAX)[0]), args.steps, wall_us] for i, Zi, s in zip(mine, Zs, group)]  # max_c e_c(X), reduced on the device
+        table = gather(recs)
+        assert table.shape[0] == n_inst, table.shape
+        barrier()
+        t1 = time.perf_counter()
+        el, tail = t1 - t0, t1 - tA
+        if dist is not None:  # the slowest rank's clock, after the region
+            tt = torch.tensor([el, tail], device=coll_dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el, tail = float(tt[0].item()), float(tt[1].item())
+        return el, tail, table
+
+    def run_group(group, seeds_g, n):
+        if group is solvers:
+            return run_steps(n)
+        for s, sd in zip(group, seeds_g):
+            s.iterate(n, None, sd)
+        for s in group:
+            s.sync()
+
+    # the first collective of a shape sets its transport up: three untimed gathers (on one rank the first RCCL gather took 2.9 ms, the
+    # second 0.28 ms, later ones 0.06-0.09 ms; the barrier 17 / 0.1 / 0.04 ms)
+    for _ in range(3):
+        gather([[i, Zi, 0.0, 0.0, 0, 0.0] for i, Zi in zip(mine, Zs)])
+        barrier()
+    reps = max(1, args.repeats)
+    regions = [timed_region(solvers, seeds) for _ in range(reps)]
+    order = sorted(range(reps), key=lambda r: regions[r][0])
+    elapsed, tail_s, table = regions[order[reps // 2]]  # the median region
+    el_all = [r[0] for r in regions]
     if os.environ.get('BENCH_DEBUG'):
-        print('[bench] loop %.0f us, records %.0f us, barrier %.0f us' % ((_tA - t0) * 1e6, (_tB - _tA) * 1e6, (t1 - _tB) * 1e6), file=sys.stderr)
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        print('[bench] regions (us): ' + ' '.join('%.0f(tail %.0f)' % (r[0] * 1e6, r[1] * 1e6) for r in regions), file=sys.stderr)
     info = solver.read(_lib.F_EXPM_INFO)
     m_used = int(info[1])
 
@@ -374,6 +410,18 @@ def main():
             b2b_first_us = None
         finally:
             os.environ.pop("MMW_BENCH_FIRST", None)
+    spmm_kind = int(solver.read(_lib.F_SPMM_KIND)[0])
+    if dtype_name == "f64":
+        operand_precision = "fp64 values, operands and accumulation"
+    elif spmm_kind == 3:
+        operand_precision = ("state (L, X, Y, sketch) in fp32; matrix-core products on 16-bit operands with fp32 accumulation: " +
+                             ("exp(L/2)R as one first-order product y = u + (L/2 - mu I)u in %d of %d steps, u read as ONE fp16 plane (identity term from the fp32 u), "
+                              "L as fp16 hi+lo of 2^20 L (one fp16 half in %d steps), certified per column against tol 1e-6 incl. the measured fp16 rounding; "
+                              % (first_iters, args.steps, first16_iters) if first_iters else "") +
+                             "Lanczos-step products on bf16 hi+lo of L and u (3 partial products); X on the pattern from bf16 hi+lo planes of y; "
+                             "`value_fp32_operands` is the same run with strictly-fp32 operands (MMW_NO_MFMA=1)")
+    else:
+        operand_precision = "fp32 values, operands and accumulation (no matrix-core product on this pattern)"
     roofline = {"bound": "hbm", "kernel": kinfo["name"] + " of the %s step" % args.expm +
                 ("; first-order epilogue (y = u + (L/2 - mu I)u, the whole exponential) in %d of %d steps" % (first_iters, args.steps) if first_iters else ""),
                 "limiter": kinfo["limiter"],
@@ -391,10 +439,16 @@ def main():
 
     out = {
         "metric": "mmw_iterations_per_sec", "value": round(n_inst * args.steps / elapsed, 2), "unit": "it/s",
+        "value_min": round(n_inst * args.steps / max(el_all), 2), "value_max": round(n_inst * args.steps / min(el_all), 2),
+        "timed_regions": reps, "value_is": "median over the timed regions (each: reset, warm-up, K steps between barriers)",
+        # the tail of the median region (objective read-back, gather of the records, closing barrier), and the rate without it:
+        # at N > 1 and short regions the difference is what the collective costs
+        "region_tail_ms": round(tail_s * 1e3, 4), "value_without_tail": round(n_inst * args.steps / max(elapsed - tail_s, 1e-9), 2),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
         "config": {"workload": args.workload, "description": desc, "K": K, "Z": Z, "D": D, "nnzL": nnzL, "C": C,
                    "eta": args.eta, "expm": args.expm, "krylov_order": m_used, "first_order_steps": first_iters, "first_order_one_half_matrix_steps": first16_iters, "rng": "device-philox4x32",
+                   "operand_precision": operand_precision,
                    "instances": n_inst, "instances_per_gpu": M,
                    "parallelism": "instance-sharded x%d" % world + (", %d resident per GPU" % M if M > 1 else "")},
         "instances_per_s": round(n_inst / elapsed, 3),  # solves of `steps` iterations per second, whole job
@@ -405,11 +459,37 @@ def main():
     }
 
     # ---- wall-clock to a converged colouring: the whole binary search on the same instance (rank 0, N = 1 only)
+    # ---- the same timed regions with strictly-fp32 operands (no 16-bit split anywhere: MMW_NO_MFMA=1 is read at handle creation)
+    if rank == 0 and world == 1 and M == 1 and dtype_name == "f32" and spmm_kind == 3 and not args.no_fp32_operands:
+        os.environ["MMW_NO_MFMA"] = "1"
+        try:
+            s32 = _lib.Solver(Z, state, nit, args.eta, dtype=dtype, device=local_rank)
+        finally:
+            os.environ.pop("MMW_NO_MFMA", None)
+        s32.set_expm(method, 12, 1e-6)
+        r32 = sorted(timed_region([s32], seeds[:1])[0] for _ in range(min(reps, 3)))
+        e32 = r32[len(r32) // 2]
+        k32 = s32.spmm_kernel_info()["name"]
+        s32.reset(nit)
+        s32.iterate(args.warmup, None, seeds[0])
+        s32.set_profile(2)
+        s32.iterate(args.steps, None, seeds[0])
+        kt32 = s32.kernel_times()
+        s32.set_profile(False)
+        us32 = kt32["spmm"][0] / max(kt32["spmm"][1], 1)
+        out["value_fp32_operands"] = round(args.steps / e32, 2)
+        out["fp32_operands"] = {"value": round(args.steps / e32, 2), "unit": "it/s", "ms_per_step": round(e32 / args.steps * 1e3, 4), "spmm_kernel": k32,
+                                "spmm_avg_launch_us": round(us32, 2), "spmm_launches_per_step": round(kt32["spmm"][1] / max(args.steps, 1), 2),
+                                "spmm_roofline_frac": round(b_spmm / (us32 * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if us32 > 0 else None}
+        s32.close()
+
     if rank == 0 and world == 1 and M == 1 and not args.no_coloring:
         for s in solvers[1:]:
             s.close()
-        out["coloring"] = coloring_block(state, dtype_name, args.coloring_nit, args.eta, warm=not args.coloring_cold, geometry=geometry0,
-                                         speculate=args.coloring_speculate)
+        # reference semantics first (cold probes): THE colouring figure; the warm-started search is an opt-in variant, labelled as such
+        out["coloring"] = coloring_block(state, dtype_name, args.coloring_nit, args.eta, warm=False, geometry=geometry0, speculate=args.coloring_speculate)
+        if not args.no_coloring_warm:
+            out["coloring_warm_start"] = coloring_block(state, dtype_name, args.coloring_nit, args.eta, warm=True, geometry=geometry0)
 
     # ---- CPU baseline: the oracle on this host, bounded sample of the same instance (rank 0, N = 1 only)
     if rank == 0 and world == 1 and args.cpu_iters != 0:

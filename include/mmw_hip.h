@@ -147,6 +147,14 @@ int mmw_set_eta(mmw_solver* s, double eta);
  */
 int mmw_iterate(mmw_solver* s, int32_t n, const double* randv, uint64_t seed);
 int mmw_sync(mmw_solver* s);
+/*
+ * mmw_sketch: the row-normalised (K, D) sketch the device generator draws for `iteration` of a run with `seed` (what
+ * np.random.randn + the row normalisation of mmw.py:226-227 are to the reference).  The generator is counter-based (Philox4x32-10
+ * keyed by seed, counter = iteration, row, column), so the block is exactly the one mmw_iterate(n, NULL, seed) multiplied in that
+ * iteration, in whatever chunk it ran: parity tests hand it to the oracle to follow a device-RNG run.  out: K*D float64, row-major.
+ * Waits for enqueued work; does not touch the iterate.
+ */
+int mmw_sketch(mmw_solver* s, uint64_t seed, int32_t iteration, double* out, int64_t n);
 
 int mmw_read_f64(mmw_solver* s, int which, double* out, int64_t n);
 int mmw_read_i32(mmw_solver* s, int which, int32_t* out, int64_t n);

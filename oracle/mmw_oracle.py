@@ -201,6 +201,10 @@ class MMWOracle:
 
     `sketch(i, K, D)` must return the (K, D) row-normalised sketch of iteration i (parity mode:
     the recorded draws; baseline mode: `sketch_rows(np.random.randn(K, D))` like mmw.py:226).
+
+    `keep_trace`: True keeps every iteration's quantities, a collection of iteration indices only those (long
+    full-size runs).  Besides the per-iteration values the trace holds, per kept iteration i, the running sums
+    mmw.py:77-78 hold when iteration i + 1 starts ("xsum" / "ysum": X_0 + ... + X_{i+1}, same for Y).
     """
 
     def __init__(self, nit=100, rank_radio=2, eta=0.1, log_gap=False, dual_as_executed=False, expm=expm_half):
@@ -220,7 +224,9 @@ class MMWOracle:
         xval[p.diag_pos] = 1.0
         xavg = np.zeros(p.nnzL)
         yavg = np.zeros(C)
-        tr = {"e_this": [], "e_accu": [], "Y": [], "lval": [], "xval": [], "X_half": [], "gap": []}
+        tr = {"e_this": [], "e_accu": [], "Y": [], "lval": [], "xval": [], "X_half": [], "gap": [], "xsum": [], "ysum": [], "iters": []}
+        keep_all = keep_trace is True
+        keep_set = set() if isinstance(keep_trace, bool) else set(int(i) for i in keep_trace)
         for i in range(self.nit):
             xavg += xval
             yavg += Y
@@ -236,7 +242,10 @@ class MMWOracle:
             lval = lval - loss_values(p, Y) * eta
             X_half = self.expm(p.csr(lval / 2.0), sketch(i, K, D))
             xval = x_on_pattern(p, X_half)
-            if keep_trace:
+            if keep_all or i in keep_set:
+                tr["iters"].append(i)
+                tr["xsum"].append(xavg + xval)
+                tr["ysum"].append(yavg + Y)
                 tr["e_this"].append(e_this)
                 tr["e_accu"].append(e_accu.copy())
                 tr["Y"].append(Y)

@@ -21,7 +21,7 @@ KERNEL_CLASSES = ["spmm", "sddmm", "dual", "loss", "krylov_vec", "sketch", "proj
 I_L_INDPTR, I_L_INDICES, I_ST_INDPTR, I_ST_INDICES, I_GAIN_X, I_GAIN_Y, I_ASSO_X, I_ASSO_Y, I_DIAG_POS, I_ASSO_POS = range(10)
 
 EXPORTS = ["mmw_last_error", "mmw_version", "mmw_device_count", "mmw_create", "mmw_destroy", "mmw_sizes", "mmw_set_expm",
-           "mmw_set_timing", "mmw_set_profile", "mmw_bench_spmm", "mmw_reset", "mmw_set_slots", "mmw_set_slots_warm", "mmw_set_eta", "mmw_iterate", "mmw_sync", "mmw_read_f64", "mmw_read_i32", "mmw_gap",
+           "mmw_set_timing", "mmw_set_profile", "mmw_bench_spmm", "mmw_reset", "mmw_set_slots", "mmw_set_slots_warm", "mmw_set_eta", "mmw_iterate", "mmw_sync", "mmw_sketch", "mmw_read_f64", "mmw_read_i32", "mmw_gap",
            "mmw_factor", "mmw_expm_apply", "mmw_sym_eig", "mmw_round", "mmw_env_create", "mmw_env_destroy", "mmw_env_sizes", "mmw_env_state",
            "mmw_env_evaluate"]
 
@@ -62,6 +62,7 @@ def lib():
     L.mmw_set_eta.argtypes = [C.c_void_p, C.c_double]
     L.mmw_iterate.argtypes = [C.c_void_p, C.c_int32, p_f64, C.c_uint64]
     L.mmw_sync.argtypes = [C.c_void_p]
+    L.mmw_sketch.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, p_f64, C.c_int64]
     L.mmw_read_f64.argtypes = [C.c_void_p, C.c_int, p_f64, C.c_int64]
     L.mmw_read_i32.argtypes = [C.c_void_p, C.c_int, p_i32, C.c_int64]
     L.mmw_gap.argtypes = [C.c_void_p, p_f64]
@@ -221,6 +222,12 @@ class Solver:
 
     def sync(self):
         check(lib().mmw_sync(self._h))
+
+    def sketch(self, seed, iteration):
+        """The (K, D) sketch the device generator draws for `iteration` of a run with `seed` (counter-based: exact, any chunking)."""
+        out = np.empty((self.K, self.D), dtype=np.float64)
+        check(lib().mmw_sketch(self._h, C.c_uint64(int(seed)), int(iteration), _pd(out), int(out.size)))
+        return out
 
     _LEN = {F_Y: "C", F_E_ACCU: "C", F_E_THIS: "C", F_LVAL: "nnzL", F_XVAL: "nnzL", F_XAVG: "nnzL", F_YAVG: "C",
             F_S_SUM: "K", F_NORM_H: "K", F_ST_DATA: "nnzST"}

@@ -59,12 +59,7 @@ inline int spmm_launch(hipStream_t st, int K, const BlockLayout& lay, int nblk, 
 // different phases interleave better than two long ones in lockstep: whole blocks first and only the last partial
 // round cut into pieces (MMW_SCHED=2) moves 40 % fewer bytes and measures 5 % slower.
 inline Blk2Sched blk2_schedule(int nb, int ntiles) {
-    static int slots = 0;
-    if (!slots) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        slots = 2 * (cus > 0 ? cus : 256);
-    }
+    const int slots = 2 * device_cus();
     Blk2Sched s;
     static const bool two_phase = getenv("MMW_SCHED") && atoi(getenv("MMW_SCHED")) == 2;
     if (!two_phase) {
@@ -99,11 +94,7 @@ inline int spmm_blk_launch(hipStream_t st, const BlkDev& B, int Dpad, const T* v
         const Blk2Sched sched = blk2_schedule(B.nb, ntiles);
         const int rem = B.nb - sched.nfull;
         const int grid = sched.grid1 + ((rem * sched.groups_tail + 7) / 8) * 8;
-        static bool attr2_set = false;  // per (T, MODE) instantiation
-        if (!attr2_set) {
-            MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_blk2<T, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS_BYTES));
-            attr2_set = true;
-        }
+        MMW_TRY(set_max_lds(reinterpret_cast<const void*>(&k_spmm_blk2<T, MODE>), B2_LDS_BYTES));
         hipLaunchKernelGGL((k_spmm_blk2<T, MODE>), dim3(grid), dim3(B2_THREADS), B2_LDS_BYTES, st, B, Dpad, ntiles, sched, val_blk, in, out, F, X2, c1, c2, c3, partial, partial_o2, plan, step, g_blk_stamps);
         MMW_HIP(hipGetLastError());
         return MMW_OK;
@@ -116,11 +107,7 @@ inline int spmm_blk_launch(hipStream_t st, const BlkDev& B, int Dpad, const T* v
     const int total = B.nb * ((ntiles + tpw - 1) / tpw);
     const int per = (total + 7) / 8;
     const size_t sh = (size_t)BLK_UNION_ROWS * BLK_TILE_BYTES + BLK_META_LDS + BLK_ROWINFO_LDS + BLK_UNOFF_LDS + (size_t)BLK_WAVES * CT * sizeof(double);
-    static bool attr_set = false;  // per (T, MODE) instantiation
-    if (!attr_set) {
-        MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_blk<T, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        attr_set = true;
-    }
+    MMW_TRY(set_max_lds(reinterpret_cast<const void*>(&k_spmm_blk<T, MODE>), (int)sh));
     hipLaunchKernelGGL((k_spmm_blk<T, MODE>), dim3(per * 8), dim3(BLK_THREADS), sh, st, B, Dpad, ntiles, tpw, val_blk, in, out, F, X2, c1, c2, c3, partial, plan, step, g_blk_stamps);
     MMW_HIP(hipGetLastError());
     return MMW_OK;
@@ -136,22 +123,12 @@ inline int spmm_mfma_launch(hipStream_t st, const MfmaDev& M, int mt, int Dpad, 
                             MfEpi epi = MfEpi{}, int* grid_out = nullptr /* workgroups launched (the first-order epilogue's trace slab) */) {
     const int ntiles = Dpad / 32;
     const int grid_x = (M.nb + 7) / 8 * 8;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    }
+    const int cus = device_cus();
 #define MMW_MF_LAUNCH(MT, NT, NW, MS, KC, NB)                                                                                          \
     do {                                                                                                                               \
-        static bool attr_set = false;                                                                                                  \
         constexpr int gtw = (NW / MS) * NT;                                                                                            \
-        constexpr int lds_bytes = mf_lds_bytes<MT, gtw, KC, NB, mf_planes(MODE), mf_apieces(MODE)>();                                                                     \
-        if (!attr_set) {                                                                                                               \
-            MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_mfma<MODE, MT, NT, NW, MS, KC, NB>),                     \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));                                       \
-            attr_set = true;                                                                                                           \
-        }                                                                                                                              \
+        constexpr int lds_bytes = mf_lds_bytes<MT, gtw, KC, NB, mf_planes(MODE), mf_apieces(MODE)>();                                  \
+        MMW_TRY(set_max_lds(reinterpret_cast<const void*>(&k_spmm_mfma<MODE, MT, NT, NW, MS, KC, NB>), lds_bytes));                    \
         hipLaunchKernelGGL((k_spmm_mfma<MODE, MT, NT, NW, MS, KC, NB>), dim3(grid_x, (ntiles + gtw - 1) / gtw), dim3(NW * 64),         \
                            lds_bytes, st, M, Dpad, plane_bytes, planes, in, out, ascale, shift, partial, partial_o2,                   \
                            plan, step, viol, g_mf_stamps, epi);                                                                        \
@@ -205,6 +182,7 @@ template <typename T> struct ExpmEngine {
     const T* val = nullptr;
     DevBuf<T> U;        // (max_order + 1) blocks of K*Dpad; block 0 is the start block
     DevBuf<T> Tm;       // A * U_j
+    DevBuf<double> partial_du;  // column sums of (u - fp16(u))^2 of the start block's fp16 plane, per sketch slab (kernels_mfma.h, first_verify)
     DevBuf<double> partial, partial_sq, partial_o2, colsum, scal, row_part;  // partial_o2: column sums of squares of the product (a-posteriori stop)  // partial: alpha numerators; partial_sq: column sums of squares
     DevBuf<ExpmPlan> plan_d;
     DevBuf<int> viol_d;
@@ -223,6 +201,13 @@ template <typename T> struct ExpmEngine {
     DevBuf<unsigned short> planes;  // bf16 hi / lo planes of the basis blocks (same bytes as the fp32 blocks)
     bool mfma_now() const { return use_mfma && use_blk && std::is_same<T, float>::value && (lay.Dpad % 32) == 0 && last_mfma_ok; }
     int spmm_slabs() const { return mfma_now() ? mf.nb : npart; }  // partial slabs the next SpMM launch writes
+    // every launch that writes `slabs` slabs of Dpad doubles into partial / partial_o2 checks this first (an undersized buffer would be
+    // an out-of-bounds device write)
+    int check_slabs(int slabs) const {
+        if ((size_t)slabs * lay.Dpad > partial.cap || (size_t)slabs * lay.Dpad > partial_o2.cap)
+            return fail(MMW_ERR_STATE, "internal: the per-block slabs of the SpMM outgrew their buffers");
+        return MMW_OK;
+    }
     bool last_mfma_ok = true;    // what the last plan the host has seen said (the matrix starts at zero)
     bool* blk_stale = nullptr;   // owner's flag: val_blk lags the CSR values
     std::function<int()> blk_refresh;  // rebuilds val_blk from the CSR values
@@ -261,9 +246,13 @@ template <typename T> struct ExpmEngine {
         for (auto& r : planes_ready) r = false;
         MMW_TRY(ensure_blocks(4));  // the basis grows on demand: the MMW loop rarely needs more than 3 vectors
         MMW_TRY(Tm.alloc(bs));
-        MMW_TRY(partial.alloc((size_t)MAX_PART * lay.Dpad));
+        // slabs one SpMM launch may write: the generic kernel's, the LDS-staged blocking's, the matrix-core blocking's (mf.nb is set once,
+        // by the owner's setup_blocking, and survives every later resize)
+        const size_t slabs = std::max((size_t)MAX_PART, std::max(use_blk ? (size_t)blk.nb : (size_t)0, use_mfma ? (size_t)mf.nb : (size_t)0));
+        MMW_TRY(partial.alloc(slabs * lay.Dpad));
         MMW_TRY(partial_sq.alloc((size_t)MAX_PART * lay.Dpad));
-        MMW_TRY(partial_o2.alloc((size_t)MAX_PART * lay.Dpad));
+        MMW_TRY(partial_du.alloc((size_t)MAX_PART * lay.Dpad));
+        MMW_TRY(partial_o2.alloc(slabs * lay.Dpad));
         npart = nblk;
         MMW_TRY(colsum.alloc(lay.Dpad));
         MMW_TRY(scal.alloc((size_t)4 * (MAX_ORDER + 2) * lay.Dpad));
@@ -355,6 +344,7 @@ template <typename T> struct ExpmEngine {
                                         const ExpmPlan* plan = nullptr, int step = 0, const unsigned short* planes_in = nullptr) {
         if constexpr (std::is_same<T, float>::value && (MODE == SPMM_PLAIN || MODE == SPMM_LANCZOS)) {
             if (planes_in && mfma_now()) {
+                MMW_TRY(check_slabs(mf.nb));
                 MMW_TRY(kbegin(KT_SPMM));
                 MMW_TRY((spmm_mfma_launch<MODE>(st, mf, mf_mt, lay.Dpad, bs * sizeof(unsigned short), reinterpret_cast<const char*>(planes_in), in, out, ascale,
                                                 shift, partial.p, apost() ? partial_o2.p : nullptr, plan, step, viol_d.p)));
@@ -457,6 +447,7 @@ template <typename T> struct ExpmEngine {
             }
             MfEpi E;
             E.y_planes = y_planes; E.dfx = dfx; E.tr_part = tr_part;
+            MMW_TRY(check_slabs(mf.nb));
             MMW_TRY(kbegin(KT_SPMM));
             if (afrag16) {
                 MfmaDev m16 = mf;

@@ -129,11 +129,7 @@ template <typename T> struct DenseWork {
             if (bjQ[q].n < pp) MMW_TRY(bjQ[q].alloc(pp));
         }
         if (bjR.n < (size_t)(M / 2) * BJ_N2 * BJ_N2) MMW_TRY(bjR.alloc((size_t)(M / 2) * BJ_N2 * BJ_N2));
-        static bool attr = false;
-        if (!attr) {
-            MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bj_apply), hipFuncAttributeMaxDynamicSharedMemorySize, BJ_APPLY_LDS));
-            attr = true;
-        }
+        MMW_TRY(set_max_lds(reinterpret_cast<const void*>(&k_bj_apply), BJ_APPLY_LDS));
         static const bool all_full = getenv("MMW_BJ_FULL") != nullptr;  // every meeting solves the whole 64 x 64 problem
         hipLaunchKernelGGL(k_bj_pad, dim3(grid_elems(pp)), dim3(BLOCK), 0, st, b, P, G.p, bjH[0].p, bjQ[0].p);
         int cur = 0, sw = 0;
@@ -165,12 +161,7 @@ template <typename T> struct DenseWork {
         const int n = (b % 2 == 0) ? b : b + 1;
         if (b <= JAC_LDS_MAX) {  // small: the whole eigensolve in one launch, matrices in LDS
             const size_t sh = ((size_t)2 * b * b + n + 2) * sizeof(double);
-            static bool attr = false;
-            if (!attr) {
-                MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jacobi_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)(((size_t)2 * JAC_LDS_MAX * JAC_LDS_MAX + JAC_LDS_MAX + 4) * sizeof(double))));
-                attr = true;
-            }
+            MMW_TRY(set_max_lds(reinterpret_cast<const void*>(&k_jacobi_lds), (int)(((size_t)2 * JAC_LDS_MAX * JAC_LDS_MAX + JAC_LDS_MAX + 4) * sizeof(double))));
             hipLaunchKernelGGL(k_jacobi_lds, dim3(1), dim3(1024), sh, st, b, G.p, diag.p, Q.p, rel_tol, max_sweeps, (int*)nullptr);
             MMW_HIP(hipGetLastError());
             calls_total += 1;

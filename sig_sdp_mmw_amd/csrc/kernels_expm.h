@@ -29,8 +29,9 @@ struct ExpmPlan {      // written by k_plan, read by every expm kernel
     int apost;         // 1: the Lanczos steps carry an a-posteriori error estimate and stop as soon as it meets tol
     int m_eff;         // steps the last application actually used (written by the combination)
     int mfma_ok;       // 1: the two-half bf16 split of the matrix-core SpMM (kernels_mfma.h) keeps the product within tol
-    int f16_ok;        // 1: so does the first-order product's single fp16 plane of u: 2^-12 max_i sum_j |a_ij| <= tol
-    int f16a_ok;       // 1: ... and with the matrix in ONE fp16 half as well (SPMM_FIRST16): 2 * 2^-12 max_i sum_j |a_ij| <= tol
+    int f16_ok;        // 1: the first-order product's single fp16 plane of u is worth launching: F16_PLANE_EXPECT absn <= tol.  A prefilter --
+                       //    the form is CERTIFIED after the fact from the plane's measured rounding (kernels_mfma.h, first_verify)
+    int f16a_ok;       // 1: ... and with the matrix in ONE fp16 half as well (SPMM_FIRST16): (F16_PLANE_EXPECT + F16_UNIT) absn <= tol
     double absn;       // max_i sum_j |a_ij| of the scaled matrix (the bound behind mfma_ok)
     // Lagged planning (the loop's optimistic chunks): the row sums of the matrix are made one iteration late, inside the DUAL
     // pass that reads the same rows, and the bounds for the matrix that is multiplied are extrapolated from the last two
@@ -42,6 +43,9 @@ struct ExpmPlan {      // written by k_plan, read by every expm kernel
     unsigned conv[MAX_ORDER + 2];  // conv[j]: float bits of the largest per-column estimate after j steps (valid once step j's scalars ran)
     unsigned first_est;  // float bits of the largest per-column error bound of the first-order form y = u + (A - mu I) u (first_order_bound)
 };
+constexpr double F16_UNIT = 4.8828125e-4;                 // 2^-11, the unit roundoff of fp16 (11 significant bits)
+constexpr double F16_PLANE_EXPECT = 0.45 * F16_UNIT;      // ||u - fp16(u)|| / ||u|| of a row-normalised Gaussian block: 0.434 * 2^-11 measured
+constexpr double F16_CA_TWO = 4.8e-7;                      // the matrix as fp16 hi + lo: 2 * 2^-22 relative per entry
 // exp(A')u = u + A'u + R with ||R|| <= sum_{k>=2} rho^(k-1) ||A'u|| / k! <= ||A'u|| (rho/2) e^rho for any rho >= ||A'||_2 (the 1-norm bound of
 // the symmetric A' is one), and ||exp(A')u|| >= e^-rho ||u||: the relative error of the first-order form is at most q (rho/2) e^(2 rho),
 // q = ||A'u|| / ||u|| measured on the column.
@@ -1369,7 +1373,8 @@ __device__ __forceinline__ void plan_body(int K, int method, int max_order, doub
         if (old.lagged && iter_seen == old.h_iter + 1) {
             const double need = pp - old.mu > pm + old.mu ? pp - old.mu : pm + old.mu;
             const double absn_seen = pp > pm ? pp : pm;
-            if (need > old.rho || (old.mfma_ok && 2.3e-5 * absn_seen > old.tol)) *viol = 1;
+            // ... and the row-sum bound every gate and certificate of that product used (mfma_ok, f16_ok, f16a_ok, first_verify)
+            if (need > old.rho || absn_seen > old.absn) *viol = 1;
         }
         // history and growth per iteration
         p.h_iter = old.h_iter; p.h_pp = old.h_pp; p.h_pm = old.h_pm; p.h_mu = old.h_mu;
@@ -1414,8 +1419,8 @@ __device__ __forceinline__ void plan_body(int K, int method, int max_order, doub
         // matrix-core SpMM: ||dT||_F <= 3 * 2^-17 || |A| ||_2 ||U||_F and || |A| ||_2 <= max_i sum_j |a_ij| = max(pp, pm)
         p.absn = pp > pm ? pp : pm;
         p.mfma_ok = 2.3e-5 * p.absn <= tol ? 1 : 0;
-        p.f16_ok = 2.4415e-4 * p.absn <= tol && p.absn < 0.03 ? 1 : 0;  // 2^-12; and the entries times 2^20 stay inside fp16's range
-        p.f16a_ok = p.f16_ok && 2.0 * 2.4415e-4 * p.absn <= tol ? 1 : 0;
+        p.f16_ok = F16_PLANE_EXPECT * p.absn <= tol && p.absn < 0.03 ? 1 : 0;  // ... and the entries times 2^20 stay inside fp16's range
+        p.f16a_ok = p.f16_ok && (F16_PLANE_EXPECT + F16_UNIT) * p.absn <= tol ? 1 : 0;
         // the a-posteriori stop needs the shifted recurrence of the half-tile SpMM, a single substep and a geometric tail
         p.apost = apost && method == 0 && nsub == 1 && !p.overflow && r < 0.5;
         for (int i = 0; i < MAX_ORDER + 2; ++i) p.conv[i] = 0u;  // identity of the maximum; a step's entry is read only after its k_lz_scalars ran
@@ -1454,7 +1459,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_verify(int K, const doubl
         const double mu = tr / K;
         if (p.lagged && iter_seen == p.h_iter + 1) {
             const double need = pp - p.mu > pm + p.mu ? pp - p.mu : pm + p.mu;
-            if (need > p.rho || (p.mfma_ok && 2.3e-5 * (pp > pm ? pp : pm) > p.tol)) *viol = 1;
+            if (need > p.rho || (pp > pm ? pp : pm) > p.absn) *viol = 1;  // see plan_body
         }
         if (iter_seen > p.h_iter) {
             const double dt = (double)(iter_seen - p.h_iter);

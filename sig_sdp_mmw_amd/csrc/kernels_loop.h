@@ -41,11 +41,12 @@ template <typename T> struct SketchArgs {
     double* colsq_part;
     unsigned short* planes;  // optional (fp32 only): bf16 hi plane, then the lo plane K * Dpad elements further (kernels_mfma.h)
     int planes_f16;          // 1: ONE fp16 plane instead (the first-order product's operand)
+    double* dusq_part;       // with planes_f16: per-slab column sums of (u - fp16(u))^2, the MEASURED rounding of that plane (first_verify)
 };
 template <typename T, int NWAVES>
 __device__ __forceinline__ void sketch_rows(int K, int D, int Dpad, uint64_t seed, uint32_t iter, T* __restrict__ R,
                                             double* __restrict__ colsq_part, int bid, int nblocks, double* shc,
-                                            unsigned short* __restrict__ planes = nullptr, int planes_f16 = 0);
+                                            unsigned short* __restrict__ planes = nullptr, int planes_f16 = 0, double* __restrict__ dusq_part = nullptr);
 
 // ---- DUAL, step 1: per row r[k] = sum of off-diagonal X, eD; per pair eF -------------------------
 template <typename T>
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(BLOCK) void k_loss(PatternDev<T> P, const int* __re
     if ((int)blockIdx.x < sk.nblocks) {  // leading workgroups draw this iteration's sketch (same shape as k_sketch_rng: same bits)
         extern __shared__ __attribute__((aligned(16))) char smem_raw[];
         sketch_rows<T, WAVES_PER_BLOCK>(sk.K, sk.D, Dpad, sk.seed, sk.iter, sk.R, sk.colsq_part, (int)blockIdx.x, sk.nblocks,
-                                        reinterpret_cast<double*>(smem_raw), sk.planes, sk.planes_f16);
+                                        reinterpret_cast<double*>(smem_raw), sk.planes, sk.planes_f16, sk.dusq_part);
         return;
     }
     const int lead = sk.nblocks + (pa.plan ? 1 : 0);
@@ -856,16 +857,19 @@ __device__ __forceinline__ void normals16(const uint32_t (&w)[4], double (&n)[2]
 template <typename T, int NWAVES>
 __device__ __forceinline__ void sketch_rows(int K, int D, int Dpad, uint64_t seed, uint32_t iter, T* __restrict__ R,
                                             double* __restrict__ colsq_part, int bid, int nblocks, double* shc,
-                                            unsigned short* __restrict__ planes, int planes_f16) {
+                                            unsigned short* __restrict__ planes, int planes_f16, double* __restrict__ dusq_part) {
     constexpr int VEC = V16<T>::N;
     constexpr int NS = 4;  // 64 lanes x 4 steps x 16 B covers Dpad <= 1024 floats / 512 doubles
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int ngroups = Dpad / VEC;
     T csq[NS][VEC];  // a wave sums a handful of unit-norm rows: T is enough, widened once at the end
+    // what the fp16 plane of the first-order product loses, column by column: sum_rows (u - fp16(u))^2.  The certificate of that
+    // product (first_verify) uses this measured rounding instead of the format's worst case 2^-11 |u|.
+    float dsq[NS][VEC];
 #pragma unroll
     for (int i = 0; i < NS; ++i)
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) csq[i][v] = T(0);
+        for (int v = 0; v < VEC; ++v) { csq[i][v] = T(0); dsq[i][v] = 0.f; }
     // a workgroup of NWAVES waves stands for NWAVES/4 workgroups of the stand-alone kernel (same rows per wave, same slabs),
     // so the start norms do not depend on which launch drew the sketch
     constexpr int VB = NWAVES / WAVES_PER_BLOCK;
@@ -904,8 +908,12 @@ __device__ __forceinline__ void sketch_rows(int K, int D, int Dpad, uint64_t see
                 if constexpr (sizeof(T) == 4) {
                     if (planes && planes_f16) {  // the first-order product reads ONE fp16 plane
                         const size_t o = ((size_t)row * Dpad + (size_t)p * VEC) >> 2;
-                        reinterpret_cast<uint2*>(planes)[o] = make_uint2((unsigned)f16_rn(n[i][0]) | ((unsigned)f16_rn(n[i][1]) << 16),
-                                                                         (unsigned)f16_rn(n[i][2]) | ((unsigned)f16_rn(n[i][3]) << 16));
+                        const unsigned short h0 = f16_rn(n[i][0]), h1 = f16_rn(n[i][1]), h2 = f16_rn(n[i][2]), h3 = f16_rn(n[i][3]);
+                        reinterpret_cast<uint2*>(planes)[o] = make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
+                        if (dusq_part) {  // exact in fp32: u and fp16(u) agree in their leading bits
+                            const float e0 = (float)n[i][0] - f16_f32(h0), e1 = (float)n[i][1] - f16_f32(h1), e2 = (float)n[i][2] - f16_f32(h2), e3 = (float)n[i][3] - f16_f32(h3);
+                            dsq[i][0] += e0 * e0; dsq[i][1] += e1 * e1; dsq[i][2] += e2 * e2; dsq[i][3] += e3 * e3;
+                        }
                     } else if (planes) {  // the matrix-core SpMM reads the block as two bf16 halves: made here, while the values are in registers
                         const unsigned a = split_bf16(n[i][0]), b = split_bf16(n[i][1]), c = split_bf16(n[i][2]), d = split_bf16(n[i][3]);
                         const size_t o = ((size_t)row * Dpad + (size_t)p * VEC) >> 2;
@@ -931,14 +939,34 @@ __device__ __forceinline__ void sketch_rows(int K, int D, int Dpad, uint64_t see
             for (int w = 0; w < WAVES_PER_BLOCK; ++w) t += shc[(h * WAVES_PER_BLOCK + w) * Dpad + c];
             colsq_part[(size_t)(bid * VB + h) * Dpad + c] = t;
         }
+        if constexpr (sizeof(T) == 4) {
+            if (dusq_part && planes && planes_f16) {  // the same fold for the rounding of the fp16 plane
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    const int p = lane + WAVE * i;
+                    if (p < ngroups)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) shc[wib * Dpad + p * VEC + v] = (double)dsq[i][v];
+                }
+                __syncthreads();
+                for (int i = threadIdx.x; i < VB * Dpad; i += NWAVES * WAVE) {
+                    const int h = i / Dpad, c = i - h * Dpad;
+                    double t = 0.0;
+                    for (int w = 0; w < WAVES_PER_BLOCK; ++w) t += shc[(h * WAVES_PER_BLOCK + w) * Dpad + c];
+                    dusq_part[(size_t)(bid * VB + h) * Dpad + c] = t;
+                }
+            }
+        }
     }
 }
 
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_sketch_rng(int K, int D, int Dpad, uint64_t seed, uint32_t iter, T* __restrict__ R,
-                                                      double* __restrict__ colsq_part, unsigned short* __restrict__ planes = nullptr, int planes_f16 = 0) {
+                                                      double* __restrict__ colsq_part, unsigned short* __restrict__ planes = nullptr, int planes_f16 = 0,
+                                                      double* __restrict__ dusq_part = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    sketch_rows<T, WAVES_PER_BLOCK>(K, D, Dpad, seed, iter, R, colsq_part, blockIdx.x, gridDim.x, reinterpret_cast<double*>(smem_raw), planes, planes_f16);
+    sketch_rows<T, WAVES_PER_BLOCK>(K, D, Dpad, seed, iter, R, colsq_part, blockIdx.x, gridDim.x, reinterpret_cast<double*>(smem_raw), planes, planes_f16, dusq_part);
 }
 
 // fragment image of the matrix-core SpMM rebuilt from the CSR values (after a snapshot restore)

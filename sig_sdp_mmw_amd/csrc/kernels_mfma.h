@@ -566,55 +566,79 @@ template <int MT> constexpr int sdm_chunk_bytes() { return 2 * sdm_rows<MT>() * 
 template <int MT> constexpr int sdm_lds_bytes() { return sdm_rows<MT>() * 4 + 2 * sdm_chunk_bytes<MT>(); }
 
 // The first-order exponential (SPMM_FIRST) is certified after the fact, off the critical path: a few spare workgroups of the next
-// iteration's k_dual_h launch (or k_first_verify at the end of a chunk) fold the column sums of o^2 (the product's slabs) and of u^2
-// (the sketch's slabs) into the largest per-column bound, leave it where the Lanczos steps leave theirs (conv[1], m_eff = 1: the
-// host's chunk logic reads the same fields) and raise the replay flag when the bound misses the tolerance or the plan does not allow
-// a single substep.  The next plan (the LOSS pass that follows) resets the fields only afterwards.
+// iteration's k_dual_h launch (or k_first_verify at the end of a chunk) fold the column sums of o^2 (the product's slabs), of u^2 and
+// of (u - fp16(u))^2 (the sketch's slabs) into the largest per-column bound, leave it where the Lanczos steps leave theirs (conv[1],
+// m_eff = 1: the host's chunk logic reads the same fields) and raise the replay flag when the bound misses the tolerance or the plan
+// does not allow a single substep.  The next plan (the LOSS pass that follows) resets the fields only afterwards.
+//
+// What is certified, per column u (relative to ||exp(A')u|| >= e^-rho ||u||):
+//   truncation      q (rho / 2) e^rho,  q = ||A'u|| / ||u|| measured           (first_order_bound)
+//   the fp16 plane  ||A (u - fp16(u))|| <= ||A||_2 ||u - fp16(u)||, with the rounding ||u - fp16(u)|| / ||u|| MEASURED by the sketch
+//                   kernel (~0.4 * 2^-11 for Gaussian rows; the format's worst case would be 2^-11 plus the subnormal flush) and
+//                   ||A||_2 <= max_i sum_j |a_ij| = absn from the plan
+//   the matrix      ||dA u|| <= || |dA| ||_2 ||u|| <= c_A absn ||u|| + n_row 2^-45 ||u||: fp16 unit roundoff 2^-11 per entry of the
+//                   one-half image (c_A = 2^-11), 2^-22 for hi + lo; entries of 2^20 L below fp16's normal range (|l| < 2^-34) err
+//                   by at most 2^-45 each, at most MF_UNION_ROWS of them in a row.
+// The fp32 accumulation of the products is not part of it (it is the arithmetic every fp32 handle computes in).
 constexpr int FV_COLS = 8;  // columns per verification workgroup (64 bytes of a slab row per thread)
+constexpr double F16_SUBNORMAL_ROW = 640.0 * 2.842170943040401e-14;  // MF_UNION_ROWS * 2^-45
 struct FirstVerify {
     ExpmPlan* plan = nullptr;  // nullptr: no verification rides in this launch
     int* viol = nullptr;
     const double* o2 = nullptr;
     const double* u2 = nullptr;
+    const double* du2 = nullptr;  // slabs of (u - fp16(u))^2, n_u2 of them
     int n_o2 = 0, n_u2 = 0, Dpad = 0;
     int nwg = 0;               // verification workgroups: Dpad / FV_COLS
+    double cA = 0.0;           // relative rounding of the matrix image the product read (see above)
+    double du_scale = 1.0;     // tests only (MMW_FV_DU_SCALE): inflates the measured rounding to force a miss
 };
 // workgroup `wg` (256 or 1024 threads) takes the columns [FV_COLS wg, FV_COLS (wg + 1)): one slab row per thread and round, fixed-order sums
 __device__ inline void first_verify(const FirstVerify& V, int wg) {
-    __shared__ double shv[2 * FV_COLS][16];
+    __shared__ double shv[3 * FV_COLS][16];
     const int BLOCK_V = (int)blockDim.x, NWV = BLOCK_V >> 6;  // 256 or 1024 threads
     const int c0 = wg * FV_COLS;
-    double acc[2 * FV_COLS];
+    double acc[3 * FV_COLS];
 #pragma unroll
-    for (int q = 0; q < 2 * FV_COLS; ++q) acc[q] = 0.0;
+    for (int q = 0; q < 3 * FV_COLS; ++q) acc[q] = 0.0;
     for (int b = threadIdx.x; b < V.n_o2; b += BLOCK_V)
 #pragma unroll
         for (int q = 0; q < FV_COLS; ++q) acc[q] += V.o2[(size_t)b * V.Dpad + c0 + q];
     for (int b = threadIdx.x; b < V.n_u2; b += BLOCK_V)
 #pragma unroll
-        for (int q = 0; q < FV_COLS; ++q) acc[FV_COLS + q] += V.u2[(size_t)b * V.Dpad + c0 + q];
+        for (int q = 0; q < FV_COLS; ++q) {
+            acc[FV_COLS + q] += V.u2[(size_t)b * V.Dpad + c0 + q];
+            acc[2 * FV_COLS + q] += V.du2[(size_t)b * V.Dpad + c0 + q];
+        }
 #pragma unroll
-    for (int q = 0; q < 2 * FV_COLS; ++q) {
+    for (int q = 0; q < 3 * FV_COLS; ++q) {
         acc[q] = wave_sum(acc[q]);
         if ((threadIdx.x & 63) == 0) shv[q][threadIdx.x >> 6] = acc[q];
     }
     __syncthreads();
     if (threadIdx.x < 64) {  // one column per lane: the double-precision tail of the eight columns runs side by side
-        double e = 0.0;
+        double e = 0.0, et = 0.0;  // the whole bound; its truncation part (what the host extrapolates with the norm's growth squared)
         if (threadIdx.x < FV_COLS) {
             const int q = (int)threadIdx.x;
-            double o2 = 0.0, u2 = 0.0;
-            for (int w = 0; w < NWV; ++w) { o2 += shv[q][w]; u2 += shv[FV_COLS + q][w]; }
-            e = u2 > 0.0 ? first_order_bound(sqrt(o2 / u2), V.plan->rho) : 0.0;
-            if (!(e >= 0.0)) e = 1e300;  // NaN
+            double o2 = 0.0, u2 = 0.0, du2 = 0.0;
+            for (int w = 0; w < NWV; ++w) { o2 += shv[q][w]; u2 += shv[FV_COLS + q][w]; du2 += shv[2 * FV_COLS + q][w]; }
+            if (u2 > 0.0) {
+                const double rho = V.plan->rho, absn = V.plan->absn;
+                et = first_order_bound(sqrt(o2 / u2), rho);
+                e = et + exp(rho) * (absn * (V.du_scale * sqrt(du2 / u2) + V.cA) + F16_SUBNORMAL_ROW);
+            }
+            if (!(e >= 0.0)) e = et = 1e300;  // NaN
         }
-        const double best = wave_max(e);
+        const double best = wave_max(e), best_t = wave_max(et);
         if (threadIdx.x == 0) {
-            float ef = (float)best;
-            if (!(ef >= 0.0f)) ef = __uint_as_float(0x7f800000u);
-            if ((double)ef < best) ef = __uint_as_float(__float_as_uint(ef) + 1u);  // round up
-            atomicMax(&V.plan->conv[1], __float_as_uint(ef));  // maxima: the order of arrival does not matter (the plan zeroed both)
-            atomicMax(&V.plan->first_est, __float_as_uint(ef));
+            auto up = [](double x) {  // float bits, rounded up
+                float f = (float)x;
+                if (!(f >= 0.0f)) f = __uint_as_float(0x7f800000u);
+                if ((double)f < x) f = __uint_as_float(__float_as_uint(f) + 1u);
+                return __float_as_uint(f);
+            };
+            atomicMax(&V.plan->conv[1], up(best));  // maxima: the order of arrival does not matter (the plan zeroed both)
+            atomicMax(&V.plan->first_est, up(best_t));
             if (wg == 0) V.plan->m_eff = 1;
             if (!(best <= V.plan->tol) || !V.plan->apost || V.plan->nsub != 1 || V.plan->overflow) *V.viol = 1;
         }

@@ -29,6 +29,7 @@ struct mmw_solver {
     virtual int set_eta(double eta) = 0;
     virtual int iterate(int32_t n, const double* randv, uint64_t seed) = 0;
     virtual int sync() = 0;
+    virtual int sketch(uint64_t seed, int32_t iteration, double* out, int64_t n) = 0;
     virtual int read_f64(int which, double* out, int64_t n) = 0;
     virtual int read_i32(int which, int32_t* out, int64_t n) = 0;
     virtual int gap(double out[3]) = 0;
@@ -90,6 +91,7 @@ template <typename T> struct Solver final : mmw_solver {
     DevBuf<double> tr1_part; // trace shares of the first-order product's workgroups (zero where none works)
     const bool first_enabled = getenv("MMW_NO_FIRST_ORDER") == nullptr;
     const bool first_a16_enabled = getenv("MMW_NO_FIRST_A16") == nullptr;
+    const double fv_du_scale = getenv("MMW_FV_DU_SCALE") ? atof(getenv("MMW_FV_DU_SCALE")) : 1.0;  // tests: inflates the measured rounding of the fp16 plane (forced miss)
     DevBuf<unsigned short> afrag16;  // the matrix as ONE fp16 half, for the first-order product while 2 * 2^-12 absn <= tol (holes zero; an image of its own)
     bool first_a16_guess = false;    // the chunk being enqueued takes that form
     long long n_first16_iters = 0;
@@ -348,8 +350,7 @@ template <typename T> struct Solver final : mmw_solver {
             {   // Work items.  A workgroup is a latency chain whose length is its number of rounds, and the launch lasts as long
                 // as its longest workgroup; the resident slots the row blocks leave free are used to cut the longest items in two
                 // (each half stages the union again).
-                int cus = 256;
-                (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+                const int cus = device_cus();
                 const int per_cu = std::max(1, std::min(2048 / SD2_THREADS, 163840 / std::max(1, HB.un8_max * B2_ROW_BYTES + 128)));
                 const size_t slots = (size_t)per_cu * (size_t)cus;
                 struct It { int rb, k0, k1; };
@@ -835,8 +836,7 @@ template <typename T> struct Solver final : mmw_solver {
             if (plan_seen) m_guess = next_launch_order(chunk);  // before the first readback of a run: the default set by reset()
             first_guess = plan_seen && first_order_ok(chunk);  // (requires that the last plan read back stopped after one step)
             if (first_guess) m_guess = 1;
-            first_a16_guess = first_guess && first_a16_enabled && afrag16.p != nullptr &&
-                              2.0 * 2.4415e-4 * eng.last.absn * growth_ratio(chunk) <= eng.last.tol;  // ExpmPlan::f16a_ok over the chunk
+            first_a16_guess = first_guess && first_a16_enabled && afrag16.p != nullptr && first_order_ok(chunk, true);
             if (warm_fresh) {  // the plan at hand belongs to the previous probe's slot count: one spare step, no first-order form
                 m_guess = std::min(eng.max_order, std::max(2, eng.last.m_eff + 1));
                 first_guess = false;
@@ -859,17 +859,21 @@ template <typename T> struct Solver final : mmw_solver {
     // The coming chunk of `ahead` iterations may take the exponential as ONE product, y = u + (L/2 - mu I) u (ExpmEngine::apply_first):
     // the last plan read back holds the bound that form would have met (first_est, from k_lz_scalars or from the form's own check); it
     // grows like rho * q ~ t^2, and the same margins as for dropping the spare Lanczos step apply.
-    bool first_order_ok(int ahead) const {
+    // The certificate (kernels_mfma.h, first_verify) adds to that truncation bound what the fp16 operands lose: the plane of u at its
+    // measured rounding (F16_PLANE_EXPECT predicts it) and the matrix image at c_A (one fp16 half: 2^-11; hi + lo: 2^-21), both times the
+    // row-sum bound absn, which grows linearly.  a16: the chunk would read the matrix as one half.
+    bool first_order_ok(int ahead, bool a16 = false) const {
         const ExpmPlan& p = eng.last;
         if (!first_enabled || sizeof(T) != 4 || !p.apost || p.m_eff != 1 || p.first_est == 0u) return false;
         union { unsigned u; float f; } e;
         e.u = p.first_est;
-        const double grow = std::pow(growth_ratio(ahead), 2.0);
-        // ... and the single fp16 plane of u must stay admissible over the chunk (ExpmPlan::f16_ok; the norm grows linearly)
-        if (!(2.4415e-4 * p.absn * std::sqrt(grow) <= p.tol) || !(p.absn * std::sqrt(grow) < 0.03)) return false;
-        // every iteration of the form is certified (a miss costs a replay of the chunk, nothing else): the bound has to meet the tolerance
-        // with a factor 4 now and a factor 2 after the growth predicted over the chunk
-        return (double)e.f <= p.tol / 4.0 && (double)e.f * grow <= p.tol / 2.0;
+        const double g1 = growth_ratio(ahead), absn_g = p.absn * g1;
+        if (!(absn_g < 0.03)) return false;  // the entries times 2^20 stay inside fp16's range
+        if (a16 ? !((F16_PLANE_EXPECT + F16_UNIT) * absn_g <= p.tol) : !(F16_PLANE_EXPECT * absn_g <= p.tol)) return false;  // ExpmPlan::f16a_ok / f16_ok over the chunk
+        // every iteration of the form is certified (a miss costs a replay of the chunk, nothing else): the truncation bound has to meet the
+        // tolerance with a factor 4 now, and the whole predicted bound with a tenth to spare after the growth over the chunk
+        const double rounding = std::exp(p.rho * g1) * (absn_g * (F16_PLANE_EXPECT + (a16 ? F16_UNIT : F16_CA_TWO)) + F16_SUBNORMAL_ROW);
+        return (double)e.f <= p.tol / 4.0 && (double)e.f * g1 * g1 + rounding <= 0.9 * p.tol;
     }
     int next_launch_order(int ahead = 0) const {
         const ExpmPlan& p = eng.last;
@@ -922,7 +926,8 @@ template <typename T> struct Solver final : mmw_solver {
         const int Dpad = eng.lay.Dpad;
         unsigned short* pl = eng.start_planes();
         hipLaunchKernelGGL((k_sketch_rng<T>), dim3(sketch_slabs()), dim3(BLOCK), lz ? (size_t)WAVES_PER_BLOCK * Dpad * sizeof(double) : 0, s, K, D, Dpad,
-                           seed, it, eng.start_block(), lz ? eng.partial_sq.p : (double*)nullptr, pl, planes_f16 ? 1 : 0);
+                           seed, it, eng.start_block(), lz ? eng.partial_sq.p : (double*)nullptr, pl, planes_f16 ? 1 : 0,
+                           planes_f16 && lz ? eng.partial_du.p : (double*)nullptr);
         eng.planes_ready[0] = pl != nullptr;
         eng.planes0_f16 = planes_f16 && pl != nullptr;
         MMW_HIP(hipGetLastError());
@@ -1001,11 +1006,12 @@ template <typename T> struct Solver final : mmw_solver {
             // this iteration's sketch is drawn by leading workgroups of the same launch (VALU work under a memory-bound pass)
             const bool rs_zeroed = rs_enabled && rsfx.p != nullptr && sddmm_mfma;  // the coming SDDMM may add its row sums to zeroed totals
             // the exponential of this iteration as one first-order product (decided per chunk, first_order_ok)
+            const bool sketch_have = !randv && sketch_done_for == (int64_t)iter && sketch_done_seed == seed;
+            // (a sketch an earlier launch already drew came without the fp16 plane and the measure of its rounding: no first-order form then)
             const bool first_it = optimistic && first_guess && m_launch == 1 && !randv && rs_zeroed && sizeof(T) == 4 && eng.mfma_now() &&
-                                  eng.method == MMW_EXPM_LANCZOS && eng.use_blk && (Dpad % 32) == 0;
+                                  eng.method == MMW_EXPM_LANCZOS && eng.use_blk && (Dpad % 32) == 0 && !sketch_have;
             SketchArgs<T> skl{};
             const bool lz_m = eng.method == MMW_EXPM_LANCZOS;
-            const bool sketch_have = !randv && sketch_done_for == (int64_t)iter && sketch_done_seed == seed;
             // (with the per-iteration phase events of mmw_set_timing on as well: the draw then counts into the LOSS phase's microseconds
             // instead of the exponential's -- the reference draws inside mmw.py:172-181 -- and the iteration's total is unchanged; a launch of
             // its own cost the class path 14 us per iteration)
@@ -1015,6 +1021,7 @@ template <typename T> struct Solver final : mmw_solver {
                 skl.colsq_part = lz_m ? eng.partial_sq.p : nullptr;
                 skl.planes = eng.start_planes();
                 skl.planes_f16 = first_it ? 1 : 0;
+                skl.dusq_part = first_it ? eng.partial_du.p : nullptr;
                 eng.planes_ready[0] = skl.planes != nullptr;
                 eng.planes0_f16 = first_it && skl.planes != nullptr;
                 sketch_done_for = (int64_t)iter; sketch_done_seed = seed; sketch_done_slabs = skl.nblocks;
@@ -1094,20 +1101,22 @@ template <typename T> struct Solver final : mmw_solver {
                     const dim3 grid((HB.nbm() + 7) / 8 * 8, (HB.m_ntile_max + SDM_GT - 1) / SDM_GT);
                     SM.tmask = b_tmask.p;
                     long long* rs_out = rs_zeroed ? rsfx.p : nullptr;  // this iteration's LOSS pass zeroed the totals
-                    static bool attr1 = false, attr2 = false;
                     if (HB.mfma_mt == 2) {
-                        if (!attr2) { MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sddmm_mfma<2>), hipFuncAttributeMaxDynamicSharedMemorySize, sdm_lds_bytes<2>())); attr2 = true; }
+                        MMW_TRY(set_max_lds(reinterpret_cast<const void*>(&k_sddmm_mfma<2>), sdm_lds_bytes<2>()));
                         hipLaunchKernelGGL((k_sddmm_mfma<2>), grid, dim3(512), sdm_lds_bytes<2>(), st, eng.mf, SM, K, Dpad,
                                            reinterpret_cast<const char*>(xh_planes.p), drow.p, trp, ntr, d_diag.p, xval.p, rs_out, dfx);
                     } else {
-                        if (!attr1) { MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sddmm_mfma<1>), hipFuncAttributeMaxDynamicSharedMemorySize, sdm_lds_bytes<1>())); attr1 = true; }
+                        MMW_TRY(set_max_lds(reinterpret_cast<const void*>(&k_sddmm_mfma<1>), sdm_lds_bytes<1>()));
                         hipLaunchKernelGGL((k_sddmm_mfma<1>), grid, dim3(256), sdm_lds_bytes<1>(), st, eng.mf, SM, K, Dpad,
                                            reinterpret_cast<const char*>(xh_planes.p), drow.p, trp, ntr, d_diag.p, xval.p, rs_out, dfx);
                     }
                     sd_done = true;
                     if (first_it) {  // certified by spare workgroups of the next iteration's k_dual_h, or by a launch of its own after the chunk's last
                         fv_pending.plan = eng.plan_d.p; fv_pending.viol = eng.viol_d.p; fv_pending.o2 = eng.partial_o2.p; fv_pending.n_o2 = eng.mf.nb;
-                        fv_pending.u2 = eng.partial_sq.p; fv_pending.n_u2 = eng.npart_start; fv_pending.Dpad = Dpad; fv_pending.nwg = Dpad / FV_COLS;
+                        fv_pending.u2 = eng.partial_sq.p; fv_pending.du2 = eng.partial_du.p; fv_pending.n_u2 = eng.npart_start; fv_pending.Dpad = Dpad;
+                        fv_pending.nwg = Dpad / FV_COLS;
+                        fv_pending.cA = first_a16_guess ? F16_UNIT : F16_CA_TWO;
+                        fv_pending.du_scale = fv_du_scale;
                     }
                     rs_ok = rs_out != nullptr;
                 }
@@ -1193,6 +1202,18 @@ template <typename T> struct Solver final : mmw_solver {
         MMW_HIP(hipStreamSynchronize(st));
         MMW_TRY(kt.flush());
         return flush_events();
+    }
+
+    // The Philox sketch of (seed, iteration) exactly as the loop draws it -- the generator is counter-based, so this is the block
+    // iteration `iteration` of a device-RNG run with that seed multiplied, whatever chunk it ran in (parity tests give it to the oracle).
+    int sketch(uint64_t seed, int32_t iteration, double* out, int64_t n) override {
+        if (host_only) return fail(MMW_ERR_STATE, "this handle was created with device -1 (host pattern only)");
+        if (iteration < 0) return fail(MMW_ERR_ARG, "mmw_sketch: iteration must be >= 0");
+        MMW_HIP(hipSetDevice(device));
+        MMW_TRY(sync());
+        hipLaunchKernelGGL((k_sketch_rng<T>), dim3(grid_rows(K)), dim3(BLOCK), 0, st, K, D, eng.lay.Dpad, seed, (uint32_t)iteration, eng.Tm.p, (double*)nullptr);
+        MMW_HIP(hipGetLastError());
+        return export_block(eng.Tm.p, out, n);
     }
 
     int export_T(const T* src, size_t n, double* out, int64_t have) {
@@ -1382,7 +1403,7 @@ int expm_apply_impl(int device, int method, int max_order, double tol, int32_t K
 extern "C" {
 
 const char* mmw_last_error(void) { return last_error_ref().c_str(); }
-int mmw_version(void) { return 210; }
+int mmw_version(void) { return 300; }
 int mmw_device_count(int* n) {
     if (!n) return fail(MMW_ERR_ARG, "null pointer");
     int c = 0;
@@ -1442,6 +1463,7 @@ int mmw_set_slots_warm(mmw_solver* s, int32_t Z, int32_t nit) { MMW_NEED(s); ret
 int mmw_set_eta(mmw_solver* s, double eta) { MMW_NEED(s); return s->set_eta(eta); }
 int mmw_iterate(mmw_solver* s, int32_t n, const double* randv, uint64_t seed) { MMW_NEED(s); return s->iterate(n, randv, seed); }
 int mmw_sync(mmw_solver* s) { MMW_NEED(s); return s->sync(); }
+int mmw_sketch(mmw_solver* s, uint64_t seed, int32_t iteration, double* out, int64_t n) { MMW_NEED(s); if (!out && n) return fail(MMW_ERR_ARG, "null output"); return s->sketch(seed, iteration, out, n); }
 int mmw_read_f64(mmw_solver* s, int which, double* out, int64_t n) { MMW_NEED(s); if (!out && n) return fail(MMW_ERR_ARG, "null output"); return s->read_f64(which, out, n); }
 int mmw_read_i32(mmw_solver* s, int which, int32_t* out, int64_t n) { MMW_NEED(s); if (!out && n) return fail(MMW_ERR_ARG, "null output"); return s->read_i32(which, out, n); }
 int mmw_gap(mmw_solver* s, double out[3]) { MMW_NEED(s); return s->gap(out); }

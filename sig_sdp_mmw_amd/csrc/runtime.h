@@ -5,8 +5,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <map>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/mmw_hip.h"
@@ -39,6 +42,33 @@ inline int fail(int code, const std::string& msg) {
         int rc__ = (expr);         \
         if (rc__ != MMW_OK) return rc__; \
     } while (0)
+
+// Per-device one-time setup.  A kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) and the CU count belong to the
+// CURRENT device, and handles of one process may sit on different devices and be driven from different host threads (bench.py's
+// resident instances, the speculative search): both are keyed by the device id and guarded.
+inline int set_max_lds(const void* fn, int bytes) {
+    int dev = 0;
+    MMW_HIP(hipGetDevice(&dev));
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, int>* done = new std::map<std::pair<const void*, int>, int>;  // never destroyed (runtime teardown order)
+    std::lock_guard<std::mutex> g(mu);
+    auto it = done->find({fn, dev});
+    if (it != done->end() && it->second >= bytes) return MMW_OK;
+    MMW_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    (*done)[{fn, dev}] = bytes;
+    return MMW_OK;
+}
+inline int device_cus() {  // compute units of the current device (256 on MI355X)
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int c = cache[dev].load(std::memory_order_relaxed);
+    if (c > 0) return c;
+    c = 256;
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+    cache[dev].store(c, std::memory_order_relaxed);
+    return c;
+}
 
 // Page-locked host staging for the large transfers of a handle (the factor handed back, the rounding's inputs).  An asynchronous
 // copy to or from pageable memory makes the runtime pin the caller's pages and unpin them later, at a moment of its own choosing:

@@ -317,13 +317,18 @@ def test_row_sums_from_the_matrix_core_sddmm_give_the_separate_pass(monkeypatch)
     b.close()
 
 
+# this graph's matrix norm grows four times faster than the benchmark instance's: the step size that keeps a whole run inside what the
+# first-order product's certificate admits (truncation + measured fp16 rounding <= tol, kernels_mfma.h first_verify)
+ETA_FIRST = 0.01
+
+
 def test_first_order_exponential_gives_the_lanczos_run(monkeypatch):
     """While one Lanczos step is accepted with room, a chunk takes exp(L/2)R as ONE product, y = u + (L/2 - mu I)u, certified after the
     fact by ||A'u|| rho/2 e^(2 rho) per column (no scalar launch, no combination).  Both forms meet the same tolerance: the runs agree to
     it, and the first-order run replays nothing."""
     state = journal_graph(16, 0.02, seed=4)
     Z, nit = 24, 60
-    a = _lib.Solver(Z, state, nit, 0.04, dtype=_lib.F32)
+    a = _lib.Solver(Z, state, nit, ETA_FIRST, dtype=_lib.F32)
     a.iterate(nit, None, seed=9)
     got = [a.read(f) for f in FIELDS]
     info = a.read(_lib.F_DUAL_INFO)
@@ -331,7 +336,7 @@ def test_first_order_exponential_gives_the_lanczos_run(monkeypatch):
     assert a.read(_lib.F_BLOCKING)[3] == 0
     a.close()
     monkeypatch.setenv("MMW_NO_FIRST_ORDER", "1")
-    b = _lib.Solver(Z, state, nit, 0.04, dtype=_lib.F32)
+    b = _lib.Solver(Z, state, nit, ETA_FIRST, dtype=_lib.F32)
     b.iterate(nit, None, seed=9)
     assert b.read(_lib.F_DUAL_INFO)[2] == 0
     for f, x in zip(FIELDS, got):
@@ -344,7 +349,7 @@ def test_first_order_exponential_is_replayed_when_its_bound_misses_the_tolerance
     in the SDDMM launch raises the replay flag and the chunk is redone with Lanczos steps -- the result is the synchronous run's."""
     state = journal_graph(16, 0.02, seed=4)
     Z, nit = 24, 48
-    a = _lib.Solver(Z, state, nit, 0.04, dtype=_lib.F32)
+    a = _lib.Solver(Z, state, nit, ETA_FIRST, dtype=_lib.F32)
     a.iterate(32, None, seed=9)
     a.sync()
     first0 = a.read(_lib.F_DUAL_INFO)[2]
@@ -356,7 +361,7 @@ def test_first_order_exponential_is_replayed_when_its_bound_misses_the_tolerance
     got = [a.read(f) for f in FIELDS]
     a.close()
     monkeypatch.setenv("MMW_SYNC_PLAN", "1")
-    b = _lib.Solver(Z, state, nit, 0.04, dtype=_lib.F32)
+    b = _lib.Solver(Z, state, nit, ETA_FIRST, dtype=_lib.F32)
     b.iterate(32, None, seed=9)
     b.set_expm(_lib.EXPM_LANCZOS, 12, 1e-9)
     b.iterate(16, None, seed=9)
