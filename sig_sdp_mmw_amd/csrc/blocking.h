@@ -74,13 +74,17 @@ struct HostBlocking {
     std::vector<int32_t> rcm_cache;     // the RCM order both blockings start from
     // matrix-core SDDMM (k_sddmm_mfma): a block's rows x union product comes out in 32 x 32 tiles (row tile, union tile); the
     // off-diagonal pattern entries of every tile, as (row in tile << 5 | column in tile) and CSR position.
-    // Tile index = m_tbase[b] + union tile * row tiles + row tile.
+    // Tile index = m_tbase[b] + union tile * row tiles + row tile.  A block's union is sorted by blocked position, so the columns
+    // that belong to EARLIER blocks come first: the tiles they fill entirely hold no listed entry and are skipped (m_desc[b][6] = first
+    // union tile to compute).
     std::vector<int32_t> m_tbase;       // [nbm+1]
     std::vector<int32_t> m_tptr;        // [tiles+1]
     std::vector<uint16_t> m_trc;        // [off-diagonal nnz]
     std::vector<uint16_t> m_tmask;      // [tiles][64]: per lane of the 32x32 accumulator (column lane & 31, rows (v & 3) + 8 (v >> 2) + 4 (lane >> 5)) bit v set where the pattern has an off-diagonal entry
-    std::vector<int32_t> m_tepos;       // [off-diagonal nnz]
-    int m_ntile_max = 0;                // most union tiles of any block
+    std::vector<int32_t> m_tepos;       // [listed entries] CSR position of the entry (row -> column) ...
+    std::vector<int32_t> m_temir;       // ... and of its mirror (column -> row): X is symmetric, every undirected edge is computed ONCE, by the block of
+                                        // the endpoint that comes first in the blocked order, and stored to both positions
+    int m_ntile_max = 0;                // most union tiles any block has to compute (from its first tile with a listed entry)
     double m_reuse = 0.0;
     int nbm() const { return (int)m_rowptr.size() - 1; }
     int nb() const { return (int)blk_rowptr.size() - 1; }
@@ -522,6 +526,12 @@ inline void build_mfma_blocking(HostBlocking& B, int K, const std::vector<int32_
         ++blk;
     }
     const int nbm = B.nbm();
+    // unions in blocked order: first the columns of earlier blocks (their edges into this block are the earlier block's to compute),
+    // then the block's own rows, then the columns of later blocks
+    std::vector<int32_t> mpos(K);
+    for (int q = 0; q < K; ++q) mpos[B.m_order[q]] = q;
+    for (int b = 0; b < nbm; ++b)
+        std::sort(un_cols.begin() + un_ptr[b], un_cols.begin() + un_ptr[b + 1], [&](int a, int c) { return mpos[a] < mpos[c]; });
     B.m_reuse = un_cols.empty() ? 0.0 : (double)nnz / (double)un_cols.size();
     B.mfma_mt = 1;
     B.m_desc.assign((size_t)nbm * 8, 0);
@@ -531,6 +541,9 @@ inline void build_mfma_blocking(HostBlocking& B, int K, const std::vector<int32_
         const int nun = un_ptr[b + 1] - un_ptr[b], rows = B.m_rowptr[b + 1] - B.m_rowptr[b];
         int32_t* d = &B.m_desc[(size_t)b * 8];
         d[0] = B.m_rowptr[b]; d[1] = rows; d[5] = nun;
+        int n_lo = 0;
+        while (n_lo < nun && mpos[un_cols[un_ptr[b] + n_lo]] < B.m_rowptr[b]) ++n_lo;
+        d[6] = n_lo / 32;  // first union tile of the SDDMM (the tile that straddles the boundary is computed)
         if (rows > 32) B.mfma_mt = 2;
         for (int u = 0; u < MF_UNION; ++u) B.m_unfixed[(size_t)b * MF_UNION + u] = un_cols[un_ptr[b] + (u < nun ? u : 0)];
         B.kbase[b + 1] = B.kbase[b] + ((nun + 15) / 16 + MF_KSTEP_PAD - 1) / MF_KSTEP_PAD * MF_KSTEP_PAD;
@@ -559,7 +572,7 @@ inline void build_mfma_blocking(HostBlocking& B, int K, const std::vector<int32_
     B.m_ntile_max = 0;
     for (int b = 0; b < nbm; ++b) {
         const int nt = (un_ptr[b + 1] - un_ptr[b] + 31) / 32;
-        B.m_ntile_max = std::max(B.m_ntile_max, nt);
+        B.m_ntile_max = std::max(B.m_ntile_max, nt - B.m_desc[(size_t)b * 8 + 6]);
         B.m_tbase[b + 1] = B.m_tbase[b] + nt * MT;
     }
     B.m_tptr.assign((size_t)B.m_tbase[nbm] + 1, 0);
@@ -570,6 +583,7 @@ inline void build_mfma_blocking(HostBlocking& B, int K, const std::vector<int32_
             fill.assign(B.m_tptr.begin(), B.m_tptr.end() - 1);
             B.m_trc.assign((size_t)B.m_tptr.back(), 0);
             B.m_tepos.assign((size_t)B.m_tptr.back(), -1);
+            B.m_temir.assign((size_t)B.m_tptr.back(), -1);
             B.m_tmask.assign((size_t)B.m_tbase[nbm] * 64, 0);
         }
         run([&, pass](int b0, int b1) {
@@ -584,13 +598,18 @@ inline void build_mfma_blocking(HostBlocking& B, int K, const std::vector<int32_
                             const int ks = li >> 4, j = li & 7, lane = (rl & 31) + 32 * ((li >> 3) & 1), mt = rl >> 5;
                             B.fpos[e] = ((((B.kbase[b] + ks) * MT + mt) * 2 + (j >> 2)) * 64 + lane) * 4 + (j & 3);
                         }
-                        if (indices[e] == r) continue;  // the diagonal comes from the exact row norms
+                        if (mpos[indices[e]] <= q) continue;  // the diagonal comes from the exact row norms; an edge to an earlier position is that row's
                         const int tile = B.m_tbase[b] + (li >> 5) * MT + (rl >> 5);  // a block's tiles are its own
                         if (pass == 0) ++B.m_tptr[(size_t)tile + 1];
                         else {
                             const int w = fill[tile]++;
                             B.m_trc[w] = (uint16_t)(((rl & 31) << 5) | (li & 31));
                             B.m_tepos[w] = e;
+                            {   // the mirror entry (column -> row): the pattern is symmetric and its rows are sorted
+                                const int c = indices[e];
+                                const int32_t* lo = std::lower_bound(indices.data() + indptr[c], indices.data() + indptr[c + 1], r);
+                                B.m_temir[w] = (int32_t)(lo - indices.data());
+                            }
                             const int r5 = rl & 31;  // accumulator slot of (row r5, column li & 31): lane = column + 32 ((r5 >> 2) & 1), register (r5 & 3) + 4 (r5 >> 3)
                             B.m_tmask[(size_t)tile * 64 + (li & 31) + 32 * ((r5 >> 2) & 1)] |= (uint16_t)(1u << ((r5 & 3) + 4 * (r5 >> 3)));
                         }
@@ -742,8 +761,11 @@ inline std::string verify_mfma_blocking(const HostBlocking& B, int K, const std:
     }
     for (int64_t e = 0; e < nnz; ++e)
         if (B.fpos[e] < 0) return "a CSR entry has no fragment position";
-    // SDDMM tile lists: every off-diagonal entry exactly once, in the tile its (row, union index) falls into
+    // SDDMM tile lists: every undirected edge exactly once -- listed with the endpoint that comes first in the blocked order as its
+    // row --, in the tile its (row, union index) falls into, with the CSR position of its mirror; no entry below a block's first tile
     std::vector<char> seen_e((size_t)nnz, 0);
+    std::vector<int32_t> mpos(K);
+    for (int q = 0; q < K; ++q) mpos[B.m_order[q]] = q;
     int64_t listed = 0;
     for (int b = 0; b < nbm; ++b) {
         const int32_t* d = &B.m_desc[(size_t)b * 8];
@@ -751,6 +773,7 @@ inline std::string verify_mfma_blocking(const HostBlocking& B, int K, const std:
         if (B.m_tbase[b + 1] - B.m_tbase[b] != nt * MT) return "tile count of a matrix-core block is off";
         for (int t = B.m_tbase[b]; t < B.m_tbase[b + 1]; ++t) {
             const int ut = (t - B.m_tbase[b]) / MT, mt = (t - B.m_tbase[b]) % MT;
+            if (ut < d[6] && B.m_tptr[t + 1] != B.m_tptr[t]) return "a tile below the block's first SDDMM tile holds entries";
             int bits = 0;  // the accumulator mask of the tile marks exactly the listed entries
             for (int l = 0; l < 64; ++l) bits += __builtin_popcount((unsigned)B.m_tmask[(size_t)t * 64 + l]);
             if (B.m_tmask.size() < (size_t)(t + 1) * 64 || bits != B.m_tptr[t + 1] - B.m_tptr[t]) return "accumulator mask of a tile does not match its list";
@@ -765,10 +788,14 @@ inline std::string verify_mfma_blocking(const HostBlocking& B, int K, const std:
                 if (rl >= d[1] || li >= nun) return "tile list entry outside its block";
                 const int r = B.m_order[d[0] + rl];
                 if (e < indptr[r] || e >= indptr[r + 1] || indices[e] != B.m_unfixed[(size_t)b * MF_UNION + li] || indices[e] == r) return "tile list entry addresses the wrong (row, column)";
+                if (mpos[indices[e]] <= mpos[r]) return "tile list entry is not the first endpoint's";
+                const int m = B.m_temir[w], c = indices[e];
+                if (m < indptr[c] || m >= indptr[c + 1] || indices[m] != r || seen_e[m]) return "mirror of a tile list entry is wrong";
+                seen_e[m] = 1;
             }
         }
     }
-    if (listed != nnz - K) return "the tile lists do not hold every off-diagonal entry";
+    if (2 * listed != nnz - K) return "the tile lists do not hold every undirected edge once";
     return "";
 }
 

@@ -348,7 +348,7 @@ __global__ __launch_bounds__(BLOCK) void k_hweights(int K, const T* __restrict__
 // One thread per stored entry (row ids from `lrow`): every array is read fully coalesced, the only gathers
 // are the two dual weights of a gain edge.
 template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_loss(PatternDev<T> P, const int* __restrict__ lrow, const T* __restrict__ Y,
+__global__ __launch_bounds__(BLOCK, (sizeof(T) == 4 ? 7 : 4)) void k_loss(PatternDev<T> P, const int* __restrict__ lrow, const T* __restrict__ Y,
                                                 const T* __restrict__ wH, const double* __restrict__ scal, T* __restrict__ lval,
                                                 double eta, const int* __restrict__ bpos, T* __restrict__ lval_blk,
                                                 const T* __restrict__ xval = nullptr, T* __restrict__ xavg = nullptr,
@@ -863,13 +863,21 @@ __device__ __forceinline__ void sketch_rows(int K, int D, int Dpad, uint64_t see
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int ngroups = Dpad / VEC;
     T csq[NS][VEC];  // a wave sums a handful of unit-norm rows: T is enough, widened once at the end
-    // what the fp16 plane of the first-order product loses, column by column: sum_rows (u - fp16(u))^2.  The certificate of that
-    // product (first_verify) uses this measured rounding instead of the format's worst case 2^-11 |u|.
-    float dsq[NS][VEC];
 #pragma unroll
     for (int i = 0; i < NS; ++i)
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) { csq[i][v] = T(0); dsq[i][v] = 0.f; }
+        for (int v = 0; v < VEC; ++v) csq[i][v] = T(0);
+    // What the fp16 plane of the first-order product loses, column by column: sum_rows (u - fp16(u))^2.  The certificate of that
+    // product (first_verify) uses this measured rounding instead of the format's worst case 2^-11 |u|.  The sums are kept in LDS
+    // (Dpad 64-bit words behind the column-square slabs, one LDS add per element): sixteen more accumulators per lane took the LOSS pass
+    // this body rides in from 7 to 5 waves per SIMD (72 -> 87 registers, 22.9 -> 25.7 us).  The adds are 2^-60 fixed-point INTEGERS,
+    // each term rounded up: the sum does not depend on the order the waves arrive in, and it is an upper bound.
+    unsigned long long* shd = reinterpret_cast<unsigned long long*>(shc + (size_t)NWAVES * Dpad);
+    const bool measure = sizeof(T) == 4 && dusq_part != nullptr && planes != nullptr && planes_f16 != 0;
+    if (measure) {
+        for (int i = threadIdx.x; i < (NWAVES / WAVES_PER_BLOCK) * Dpad; i += NWAVES * WAVE) shd[i] = 0ull;
+        __syncthreads();
+    }
     // a workgroup of NWAVES waves stands for NWAVES/4 workgroups of the stand-alone kernel (same rows per wave, same slabs),
     // so the start norms do not depend on which launch drew the sketch
     constexpr int VB = NWAVES / WAVES_PER_BLOCK;
@@ -910,9 +918,12 @@ __device__ __forceinline__ void sketch_rows(int K, int D, int Dpad, uint64_t see
                         const size_t o = ((size_t)row * Dpad + (size_t)p * VEC) >> 2;
                         const unsigned short h0 = f16_rn(n[i][0]), h1 = f16_rn(n[i][1]), h2 = f16_rn(n[i][2]), h3 = f16_rn(n[i][3]);
                         reinterpret_cast<uint2*>(planes)[o] = make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
-                        if (dusq_part) {  // exact in fp32: u and fp16(u) agree in their leading bits
+                        if (measure) {  // the differences are exact in fp32: u and fp16(u) agree in their leading bits
                             const float e0 = (float)n[i][0] - f16_f32(h0), e1 = (float)n[i][1] - f16_f32(h1), e2 = (float)n[i][2] - f16_f32(h2), e3 = (float)n[i][3] - f16_f32(h3);
-                            dsq[i][0] += e0 * e0; dsq[i][1] += e1 * e1; dsq[i][2] += e2 * e2; dsq[i][3] += e3 * e3;
+                            unsigned long long* dst = shd + (wib / WAVES_PER_BLOCK) * Dpad + p * VEC;
+                            constexpr float FX = 1152921504606846976.0f;  // 2^60; |e| <= 2^-11, so a term stays below 2^38
+                            atomicAdd(dst, (unsigned long long)ceilf(e0 * e0 * FX)); atomicAdd(dst + 1, (unsigned long long)ceilf(e1 * e1 * FX));
+                            atomicAdd(dst + 2, (unsigned long long)ceilf(e2 * e2 * FX)); atomicAdd(dst + 3, (unsigned long long)ceilf(e3 * e3 * FX));
                         }
                     } else if (planes) {  // the matrix-core SpMM reads the block as two bf16 halves: made here, while the values are in registers
                         const unsigned a = split_bf16(n[i][0]), b = split_bf16(n[i][1]), c = split_bf16(n[i][2]), d = split_bf16(n[i][3]);
@@ -939,25 +950,11 @@ __device__ __forceinline__ void sketch_rows(int K, int D, int Dpad, uint64_t see
             for (int w = 0; w < WAVES_PER_BLOCK; ++w) t += shc[(h * WAVES_PER_BLOCK + w) * Dpad + c];
             colsq_part[(size_t)(bid * VB + h) * Dpad + c] = t;
         }
-        if constexpr (sizeof(T) == 4) {
-            if (dusq_part && planes && planes_f16) {  // the same fold for the rounding of the fp16 plane
-                __syncthreads();
-#pragma unroll
-                for (int i = 0; i < NS; ++i) {
-                    const int p = lane + WAVE * i;
-                    if (p < ngroups)
-#pragma unroll
-                        for (int v = 0; v < VEC; ++v) shc[wib * Dpad + p * VEC + v] = (double)dsq[i][v];
-                }
-                __syncthreads();
-                for (int i = threadIdx.x; i < VB * Dpad; i += NWAVES * WAVE) {
-                    const int h = i / Dpad, c = i - h * Dpad;
-                    double t = 0.0;
-                    for (int w = 0; w < WAVES_PER_BLOCK; ++w) t += shc[(h * WAVES_PER_BLOCK + w) * Dpad + c];
-                    dusq_part[(size_t)(bid * VB + h) * Dpad + c] = t;
-                }
-            }
-        }
+    }
+    if (measure) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < VB * Dpad; i += NWAVES * WAVE)
+            dusq_part[(size_t)(bid * VB) * Dpad + i] = (double)shd[i] * 8.673617379884035e-19 * (1.0 + 2e-7);  // 2^-60; the fp32 squares were rounded
     }
 }
 

@@ -556,8 +556,9 @@ struct SdMfmaDev {
     const int* tbase;             // [nb+1] first tile of each block
     const int* tptr;              // [tiles+1] entry ranges
     const unsigned short* trc;    // row in tile << 5 | column in tile
-    const int* tepos;             // CSR position
-    const unsigned short* tmask;  // [tiles][64] accumulator mask of the pattern's entries (blocking.h, m_tmask)
+    const int* tepos;             // CSR position of the entry ...
+    const int* temir;             // ... and of its mirror: every undirected edge is computed once and stored twice (blocking.h, m_temir)
+    const unsigned short* tmask;  // [tiles][64] accumulator mask of the listed entries (blocking.h, m_tmask)
 };
 constexpr int SDM_GT = 4;   // union tiles per workgroup
 constexpr int SDM_KC = 2;   // k-steps per chunk (a 128-byte line per row: 64 bytes of hi halves, 64 of lo halves)
@@ -587,34 +588,32 @@ struct FirstVerify {
     int* viol = nullptr;
     const double* o2 = nullptr;
     const double* u2 = nullptr;
-    const double* du2 = nullptr;  // slabs of (u - fp16(u))^2, n_u2 of them
+    const double* du2 = nullptr;  // slabs of (u - fp16(u))^2, n_u2 of them; nullptr: not measured -- the format's worst case is used instead
+                                  // (|du| <= 2^-11 |u| in fp16's normal range, <= 2^-25 below it: ||du||^2 <= 2^-22 ||u||^2 + rows 2^-50)
+    int rows = 0;                 // K
     int n_o2 = 0, n_u2 = 0, Dpad = 0;
     int nwg = 0;               // verification workgroups: Dpad / FV_COLS
     double cA = 0.0;           // relative rounding of the matrix image the product read (see above)
     double du_scale = 1.0;     // tests only (MMW_FV_DU_SCALE): inflates the measured rounding to force a miss
 };
-// workgroup `wg` (256 or 1024 threads) takes the columns [FV_COLS wg, FV_COLS (wg + 1)): one slab row per thread and round, fixed-order sums
+// workgroup `wg` (256 or 1024 threads) takes the columns [FV_COLS wg, FV_COLS (wg + 1)).  Lane (q = lane & 7, slice = lane >> 3) of wave w sums
+// column q over the slab rows 8 w + slice, + 8 waves, ...: a load covers 8 rows x 64 bytes, and a wave's 24 sums meet in three strided
+// reductions (lanes of equal q) instead of 24 whole-wave ones.  Fixed order throughout.
 __device__ inline void first_verify(const FirstVerify& V, int wg) {
     __shared__ double shv[3 * FV_COLS][16];
     const int BLOCK_V = (int)blockDim.x, NWV = BLOCK_V >> 6;  // 256 or 1024 threads
     const int c0 = wg * FV_COLS;
-    double acc[3 * FV_COLS];
-#pragma unroll
-    for (int q = 0; q < 3 * FV_COLS; ++q) acc[q] = 0.0;
-    for (int b = threadIdx.x; b < V.n_o2; b += BLOCK_V)
-#pragma unroll
-        for (int q = 0; q < FV_COLS; ++q) acc[q] += V.o2[(size_t)b * V.Dpad + c0 + q];
-    for (int b = threadIdx.x; b < V.n_u2; b += BLOCK_V)
-#pragma unroll
-        for (int q = 0; q < FV_COLS; ++q) {
-            acc[FV_COLS + q] += V.u2[(size_t)b * V.Dpad + c0 + q];
-            acc[2 * FV_COLS + q] += V.du2[(size_t)b * V.Dpad + c0 + q];
-        }
-#pragma unroll
-    for (int q = 0; q < 3 * FV_COLS; ++q) {
-        acc[q] = wave_sum(acc[q]);
-        if ((threadIdx.x & 63) == 0) shv[q][threadIdx.x >> 6] = acc[q];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, q8 = lane & 7, sl = lane >> 3;
+    double a_o2 = 0.0, a_u2 = 0.0, a_du = 0.0;
+    for (int b = wv * 8 + sl; b < V.n_o2; b += NWV * 8) a_o2 += V.o2[(size_t)b * V.Dpad + c0 + q8];
+    for (int b = wv * 8 + sl; b < V.n_u2; b += NWV * 8) {
+        a_u2 += V.u2[(size_t)b * V.Dpad + c0 + q8];
+        if (V.du2) a_du += V.du2[(size_t)b * V.Dpad + c0 + q8];
     }
+    a_o2 = stride_sum(a_o2, 8);
+    a_u2 = stride_sum(a_u2, 8);
+    a_du = stride_sum(a_du, 8);
+    if (lane < FV_COLS) { shv[lane][wv] = a_o2; shv[FV_COLS + lane][wv] = a_u2; shv[2 * FV_COLS + lane][wv] = a_du; }
     __syncthreads();
     if (threadIdx.x < 64) {  // one column per lane: the double-precision tail of the eight columns runs side by side
         double e = 0.0, et = 0.0;  // the whole bound; its truncation part (what the host extrapolates with the norm's growth squared)
@@ -625,6 +624,7 @@ __device__ inline void first_verify(const FirstVerify& V, int wg) {
             if (u2 > 0.0) {
                 const double rho = V.plan->rho, absn = V.plan->absn;
                 et = first_order_bound(sqrt(o2 / u2), rho);
+                if (!V.du2) du2 = F16_UNIT * F16_UNIT * u2 + (double)V.rows * 8.881784197001252e-16;  // 2^-50
                 e = et + exp(rho) * (absn * (V.du_scale * sqrt(du2 / u2) + V.cA) + F16_SUBNORMAL_ROW);
             }
             if (!(e >= 0.0)) e = et = 1e300;  // NaN
@@ -650,8 +650,11 @@ template <int MT>
 __global__ __launch_bounds__(4 * MT * 64)
 void k_sddmm_mfma(MfmaDev M, SdMfmaDev S, int K, int Dpad, const char* __restrict__ Ypl, const float* __restrict__ d,
                   const double* __restrict__ tr_part, int ntr, const int* __restrict__ diag_pos, float* __restrict__ xval,
-                  long long* __restrict__ rsfx = nullptr /* [K], zero at launch */, const long long* __restrict__ dfx = nullptr) {
+                  long long* __restrict__ rsfx = nullptr /* [K], zero at launch */, const long long* __restrict__ dfx = nullptr,
+                  unsigned long long* __restrict__ stamps = nullptr /* diagnostic runs: 8 shader-clock sums per wave */) {
     // dfx: the row norms as 2^-40 fixed-point totals (SPMM_FIRST) instead of `d`
+    unsigned long long tk0 = 0, tk1 = 0, acc_wait = 0, acc_issue = 0, acc_comp = 0, t_pro = 0, t_red = 0, t_store = 0;
+    if (stamps) tk0 = __builtin_amdgcn_s_memtime();
     const int by = (int)blockIdx.y;  // union-tile group of this workgroup
     // rsfx: the DUAL phase's first step (mmw.py:133-134, the row sums of the off-diagonal X) leaves with the tiles: every wave sums
     // its tile's pattern entries per row straight from the accumulators, the workgroup's union tiles meet in LDS, and the part of
@@ -676,7 +679,9 @@ void k_sddmm_mfma(MfmaDev M, SdMfmaDev S, int K, int Dpad, const char* __restric
     const int* dsc = M.desc + (size_t)rb * 8;
     const int q0 = dsc[0], nrows = dsc[1], nun = dsc[5];
     const int ntile = (nun + 31) >> 5;
-    const int ut0 = by * SDM_GT;  // first union tile of this workgroup
+    // X is symmetric: an edge is computed by the block of the endpoint that comes first in the blocked order.  The union is sorted by
+    // that order, so the tiles before dsc[6] hold only columns of earlier blocks -- their edges are those blocks' -- and are skipped.
+    const int ut0 = dsc[6] + by * SDM_GT;  // first union tile of this workgroup
     if (ut0 >= ntile) return;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -745,10 +750,13 @@ void k_sddmm_mfma(MfmaDev M, SdMfmaDev S, int K, int Dpad, const char* __restric
     for (int v = 0; v < 16; ++v) acc[v] = 0.f;
     const int NC = Dpad / (16 * SDM_KC);
     issue(0);
+    if (stamps) { tk1 = __builtin_amdgcn_s_memtime(); t_pro = tk1 - tk0; }
     for (int c = 0; c < NC; ++c) {
         mf_wait_vmcnt(0);              // two buffers: chunk c is the only one outstanding here
         __builtin_amdgcn_s_barrier();  // chunk c landed for everyone; everyone left the other buffer
+        if (stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_wait += t - tk1; tk1 = t; }
         if (c + 1 < NC) issue(c + 1);
+        if (stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_issue += t - tk1; tk1 = t; }
         const char* cb = bufs + (c & 1) * CHUNK;
 #pragma unroll
         for (int kk = 0; kk < SDM_KC; ++kk) {
@@ -760,13 +768,39 @@ void k_sddmm_mfma(MfmaDev M, SdMfmaDev S, int K, int Dpad, const char* __restric
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mf_bf8, ah), __builtin_bit_cast(mf_bf8, bl), acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mf_bf8, ah), __builtin_bit_cast(mf_bf8, bh), acc, 0, 0, 0);
         }
+        if (stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_comp += t - tk1; tk1 = t; }
     }
     static_assert(NW * 4096 + 4 * 32 * MT * 4 <= 2 * CHUNK, "tiles and row-sum parts fit into the chunk buffers");
+    // the wave's entry list (CSR position, mirror position, place in the tile) is static: the first 256 entries are requested here, so
+    // that their round trip passes under the reductions, the barriers and the tile's way through LDS
+    constexpr int EPL = 4;  // entries per lane and round
+    int ep[EPL], em[EPL];
+    unsigned rc[EPL];
+    auto fetch_list = [&](int base) {
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+            const int w = base + k * 64 + lane;
+            const bool ok = w < tw1;
+            ep[k] = ok ? S.tepos[w] : -1;
+            em[k] = ok ? S.temir[w] : -1;
+            rc[k] = ok ? (unsigned)S.trc[w] : 0u;
+        }
+    };
+    fetch_list(tw0);
     float rsv[16];
+    float csum = 0.f;
     if (rsfx) {
 #pragma unroll
-        for (int v = 0; v < 16; ++v) rsv[v] = group_sum(((mk >> v) & 1u) ? acc[v] : 0.f, 32);  // over the 32 columns of the tile
+        for (int v = 0; v < 16; ++v) {
+            const float m = ((mk >> v) & 1u) ? acc[v] : 0.f;
+            csum += m;                   // the same entries seen from their columns: the mirror entries' share of THOSE rows' sums
+            rsv[v] = group_sum(m, 32);   // over the 32 columns of the tile
+        }
+        float ca, cb;
+        rows32(csum, ca, cb);            // a column's 32 rows sit in lanes c and c + 32
+        csum = ca + cb;
     }
+    if (stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_red = t - tk1; tk1 = t; }
     __syncthreads();  // every wave is done with the chunk buffers: they now hold the 32 x 32 output tiles, one per wave
     float* rsl = reinterpret_cast<float*>(bufs) + NW * 1024;  // [4 union tiles][32 MT rows] behind the tiles
     if (rsfx && (lane & 31) == 0) {
@@ -781,7 +815,21 @@ void k_sddmm_mfma(MfmaDev M, SdMfmaDev S, int K, int Dpad, const char* __restric
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    for (int w = tw0 + lane; w < tw1; w += 64) xval[S.tepos[w]] = (float)((double)tile[S.trc[w]] / tr);
+    const float inv_tr = (float)(1.0 / tr);
+    for (int base = tw0; base < tw1; base += 64 * EPL) {
+        if (base != tw0) fetch_list(base);
+#pragma unroll
+        for (int k = 0; k < EPL; ++k)
+            if (ep[k] >= 0) {
+                const float x = tile[rc[k]] * inv_tr;
+                xval[ep[k]] = x;
+                xval[em[k]] = x;
+            }
+    }
+    if (rsfx && lane < 32 && csum != 0.f) {  // (exactly zero where the column has no listed entry in this tile)
+        const long long q = __double2ll_rn((double)csum / tr * SDM_FX);
+        atomicAdd(reinterpret_cast<unsigned long long*>(rsfx) + rows_l[RA + 32 * wn + lane], (unsigned long long)q);
+    }
     if (by == 0)  // the diagonal of the block's rows from the exact row norms
         for (int i = threadIdx.x; i < nrows; i += THREADS) {
             const int row = rows_l[i];
@@ -793,6 +841,12 @@ void k_sddmm_mfma(MfmaDev M, SdMfmaDev S, int K, int Dpad, const char* __restric
             const long long q = __double2ll_rn((double)sum4 / tr * SDM_FX);
             atomicAdd(reinterpret_cast<unsigned long long*>(rsfx) + rows_l[i], (unsigned long long)q);  // integers: the order of arrival does not matter
         }
+    if (stamps && lane == 0) {
+        const unsigned long long te = __builtin_amdgcn_s_memtime();
+        t_store = te - tk1;
+        unsigned long long* o = stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wv) * 8;
+        o[0] = t_pro; o[1] = acc_wait; o[2] = acc_issue; o[3] = acc_comp; o[4] = te - tk0; o[5] = t_red; o[6] = tk0; o[7] = t_store;
+    }
 }
 
 }  // namespace mmw

@@ -84,7 +84,7 @@ template <typename T> struct Solver final : mmw_solver {
     DevBuf<ExpmPlan> sn_plan;        // plan (with its history) at the start of the pending chunk
     DevBuf<int> b_kbase, b_fpos, b_mdesc, b_munfixed, b_morder;  // matrix-core SpMM: its row blocks, CSR entry -> fragment image position
     DevBuf<unsigned> afrag;          // the matrix as bf16 hi << 16 | lo words in MFMA fragment order
-    DevBuf<int> b_tbase, b_tptr, b_tepos;  // matrix-core SDDMM: pattern entries by 32 x 32 output tile
+    DevBuf<int> b_tbase, b_tptr, b_tepos, b_temir;  // matrix-core SDDMM: pattern entries by 32 x 32 output tile
     DevBuf<unsigned short> b_trc, b_tmask, xh_planes;
     DevBuf<long long> rsfx;  // [2K] 2^-40 fixed-point totals: [0, K) row sums of the off-diagonal X, left by the matrix-core SDDMM; [K, 2K) row norms of
                              // y = exp(L/2)R from the first-order product (kernels_mfma.h).  Zeroed by every LOSS pass.
@@ -92,6 +92,9 @@ template <typename T> struct Solver final : mmw_solver {
     const bool first_enabled = getenv("MMW_NO_FIRST_ORDER") == nullptr;
     const bool first_a16_enabled = getenv("MMW_NO_FIRST_A16") == nullptr;
     const double fv_du_scale = getenv("MMW_FV_DU_SCALE") ? atof(getenv("MMW_FV_DU_SCALE")) : 1.0;  // tests: inflates the measured rounding of the fp16 plane (forced miss)
+    // the rounding of the first-order product's fp16 plane: measured by the sketch kernel (default), or the format's worst case
+    const bool fv_measure = getenv("MMW_FV_WORSTCASE") == nullptr;
+    double plane_rounding() const { return fv_measure ? F16_PLANE_EXPECT : 1.02 * F16_UNIT; }
     DevBuf<unsigned short> afrag16;  // the matrix as ONE fp16 half, for the first-order product while 2 * 2^-12 absn <= tol (holes zero; an image of its own)
     bool first_a16_guess = false;    // the chunk being enqueued takes that form
     long long n_first16_iters = 0;
@@ -423,6 +426,7 @@ template <typename T> struct Solver final : mmw_solver {
             if (!getenv("MMW_NO_MFMA_SDDMM")) {
                 MMW_TRY(b_tbase.upload(HB.m_tbase, st)); MMW_TRY(b_tptr.upload(HB.m_tptr, st)); MMW_TRY(b_trc.upload(HB.m_trc, st));
                 MMW_TRY(b_tepos.upload(HB.m_tepos, st));
+                MMW_TRY(b_temir.upload(HB.m_temir, st));
                 MMW_TRY(b_tmask.upload(HB.m_tmask, st));
                 MMW_TRY(rsfx.alloc((size_t)2 * K));
                 sddmm_mfma = true;
@@ -872,7 +876,7 @@ template <typename T> struct Solver final : mmw_solver {
         if (a16 ? !((F16_PLANE_EXPECT + F16_UNIT) * absn_g <= p.tol) : !(F16_PLANE_EXPECT * absn_g <= p.tol)) return false;  // ExpmPlan::f16a_ok / f16_ok over the chunk
         // every iteration of the form is certified (a miss costs a replay of the chunk, nothing else): the truncation bound has to meet the
         // tolerance with a factor 4 now, and the whole predicted bound with a tenth to spare after the growth over the chunk
-        const double rounding = std::exp(p.rho * g1) * (absn_g * (F16_PLANE_EXPECT + (a16 ? F16_UNIT : F16_CA_TWO)) + F16_SUBNORMAL_ROW);
+        const double rounding = std::exp(p.rho * g1) * (absn_g * (plane_rounding() + (a16 ? F16_UNIT : F16_CA_TWO)) + F16_SUBNORMAL_ROW);
         return (double)e.f <= p.tol / 4.0 && (double)e.f * g1 * g1 + rounding <= 0.9 * p.tol;
     }
     int next_launch_order(int ahead = 0) const {
@@ -925,9 +929,9 @@ template <typename T> struct Solver final : mmw_solver {
         const bool lz = eng.method == MMW_EXPM_LANCZOS;
         const int Dpad = eng.lay.Dpad;
         unsigned short* pl = eng.start_planes();
-        hipLaunchKernelGGL((k_sketch_rng<T>), dim3(sketch_slabs()), dim3(BLOCK), lz ? (size_t)WAVES_PER_BLOCK * Dpad * sizeof(double) : 0, s, K, D, Dpad,
+        hipLaunchKernelGGL((k_sketch_rng<T>), dim3(sketch_slabs()), dim3(BLOCK), lz ? (size_t)(WAVES_PER_BLOCK + 1) * Dpad * sizeof(double) : 0, s, K, D, Dpad,
                            seed, it, eng.start_block(), lz ? eng.partial_sq.p : (double*)nullptr, pl, planes_f16 ? 1 : 0,
-                           planes_f16 && lz ? eng.partial_du.p : (double*)nullptr);
+                           planes_f16 && lz && fv_measure ? eng.partial_du.p : (double*)nullptr);
         eng.planes_ready[0] = pl != nullptr;
         eng.planes0_f16 = planes_f16 && pl != nullptr;
         MMW_HIP(hipGetLastError());
@@ -1021,7 +1025,7 @@ template <typename T> struct Solver final : mmw_solver {
                 skl.colsq_part = lz_m ? eng.partial_sq.p : nullptr;
                 skl.planes = eng.start_planes();
                 skl.planes_f16 = first_it ? 1 : 0;
-                skl.dusq_part = first_it ? eng.partial_du.p : nullptr;
+                skl.dusq_part = first_it && fv_measure ? eng.partial_du.p : nullptr;
                 eng.planes_ready[0] = skl.planes != nullptr;
                 eng.planes0_f16 = first_it && skl.planes != nullptr;
                 sketch_done_for = (int64_t)iter; sketch_done_seed = seed; sketch_done_slabs = skl.nblocks;
@@ -1030,7 +1034,7 @@ template <typename T> struct Solver final : mmw_solver {
             const bool mf_it = eng.mfma_now() && eng.method == MMW_EXPM_LANCZOS;
             if (mf_it) lblk_stale = true;
             const PlanArgs pl_loss = fused_dual ? pa : PlanArgs{};  // the fused pass has no softmax pass B to lend the planning a workgroup
-            hipLaunchKernelGGL((k_loss<T>), dim3(gl + skl.nblocks + (pl_loss.plan ? 1 : 0)), dim3(BLOCK), skl.nblocks && lz_m ? (size_t)WAVES_PER_BLOCK * Dpad * sizeof(double) : 0,
+            hipLaunchKernelGGL((k_loss<T>), dim3(gl + skl.nblocks + (pl_loss.plan ? 1 : 0)), dim3(BLOCK), skl.nblocks && lz_m ? (size_t)(WAVES_PER_BLOCK + 1) * Dpad * sizeof(double) : 0,
                                st, P, d_lrow.p, fused_dual ? yun.p : Y.p, wH.p, scal.p, lval.p, eta,
                                (const int*)(eng.use_blk && !mf_it ? b_bpos.p : nullptr), lval_blk.p,
                                (const T*)(xavg_deferred ? xval.p : nullptr), xavg_deferred ? xavg.p : (T*)nullptr, skl, Dpad,
@@ -1094,26 +1098,70 @@ template <typename T> struct Solver final : mmw_solver {
             if constexpr (sizeof(T) == 4) {
                 if (sd_mf) {
                     SdMfmaDev SM;
-                    SM.tbase = b_tbase.p; SM.tptr = b_tptr.p; SM.trc = b_trc.p; SM.tepos = b_tepos.p;
+                    SM.tbase = b_tbase.p; SM.tptr = b_tptr.p; SM.trc = b_trc.p; SM.tepos = b_tepos.p; SM.temir = b_temir.p;
                     const long long* dfx = first_it ? rsfx.p + K : nullptr;
                     const double* trp = first_it ? tr1_part.p : tr_part.p;
                     const int ntr = first_it ? ntr1 : gr;
                     const dim3 grid((HB.nbm() + 7) / 8 * 8, (HB.m_ntile_max + SDM_GT - 1) / SDM_GT);
                     SM.tmask = b_tmask.p;
                     long long* rs_out = rs_zeroed ? rsfx.p : nullptr;  // this iteration's LOSS pass zeroed the totals
+                    // MMW_SD_STAMPS=1 (developer aid): per-wave phase clocks of the last iteration's launch, printed to stderr
+                    DevBuf<unsigned long long> sdm_stamps;
+                    const size_t n_st = (size_t)grid.x * grid.y * 16 * 8;
+                    const bool want_st = it + 1 == n && getenv("MMW_SD_STAMPS") != nullptr;
+                    if (want_st) {
+                        MMW_TRY(sdm_stamps.alloc(n_st));
+                        MMW_HIP(hipMemsetAsync(sdm_stamps.p, 0, n_st * sizeof(unsigned long long), st));
+                    }
                     if (HB.mfma_mt == 2) {
                         MMW_TRY(set_max_lds(reinterpret_cast<const void*>(&k_sddmm_mfma<2>), sdm_lds_bytes<2>()));
                         hipLaunchKernelGGL((k_sddmm_mfma<2>), grid, dim3(512), sdm_lds_bytes<2>(), st, eng.mf, SM, K, Dpad,
-                                           reinterpret_cast<const char*>(xh_planes.p), drow.p, trp, ntr, d_diag.p, xval.p, rs_out, dfx);
+                                           reinterpret_cast<const char*>(xh_planes.p), drow.p, trp, ntr, d_diag.p, xval.p, rs_out, dfx, sdm_stamps.p);
                     } else {
                         MMW_TRY(set_max_lds(reinterpret_cast<const void*>(&k_sddmm_mfma<1>), sdm_lds_bytes<1>()));
                         hipLaunchKernelGGL((k_sddmm_mfma<1>), grid, dim3(256), sdm_lds_bytes<1>(), st, eng.mf, SM, K, Dpad,
-                                           reinterpret_cast<const char*>(xh_planes.p), drow.p, trp, ntr, d_diag.p, xval.p, rs_out, dfx);
+                                           reinterpret_cast<const char*>(xh_planes.p), drow.p, trp, ntr, d_diag.p, xval.p, rs_out, dfx, sdm_stamps.p);
+                    }
+                    if (want_st) {
+                        std::vector<unsigned long long> h(n_st);
+                        MMW_HIP(hipMemcpyAsync(h.data(), sdm_stamps.p, n_st * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+                        MMW_HIP(hipStreamSynchronize(st));
+                        double sum[8] = {0}, life_max = 0;
+                        unsigned long long tmin = ~0ull, tmax = 0;
+                        int nw = 0;
+                        for (size_t w = 0; w < n_st / 8; ++w) {
+                            const unsigned long long* q = &h[w * 8];
+                            if (!q[4]) continue;
+                            ++nw;
+                            for (int k = 0; k < 8; ++k) sum[k] += (double)q[k];
+                            life_max = std::max(life_max, (double)q[4]);
+                            tmin = std::min(tmin, q[6]);
+                            tmax = std::max(tmax, q[6] + q[4]);
+                        }
+                        {   // the slowest twentieth of the waves: where their time went
+                            std::vector<std::pair<unsigned long long, size_t>> byl;
+                            for (size_t w = 0; w < n_st / 8; ++w) if (h[w * 8 + 4]) byl.push_back({h[w * 8 + 4], w});
+                            std::sort(byl.rbegin(), byl.rend());
+                            const size_t top = std::max<size_t>(1, byl.size() / 20);
+                            double ts[8] = {0};
+                            for (size_t i = 0; i < top && i < byl.size(); ++i) for (int k = 0; k < 8; ++k) ts[k] += (double)h[byl[i].second * 8 + k];
+                            if (!byl.empty())
+                                fprintf(stderr, "[sddmm stamps] slowest %zu waves: prologue %.0f, wait+barrier %.0f, issue %.0f, reads+products %.0f, sums %.0f, stores %.0f, lifetime %.0f; by (wg.y): ", top,
+                                        ts[0] / top, ts[1] / top, ts[2] / top, ts[3] / top, ts[5] / top, ts[7] / top, ts[4] / top);
+                            int cnt[8] = {0};
+                            for (size_t i = 0; i < top && i < byl.size(); ++i) { const size_t wg = byl[i].second / (size_t)(4 * HB.mfma_mt); const unsigned y = (unsigned)(wg / grid.x); if (y < 8) ++cnt[y]; }
+                            for (unsigned y = 0; y < grid.y && y < 8; ++y) fprintf(stderr, "%d ", cnt[y]);
+                            fprintf(stderr, "\n");
+                        }
+                        if (nw)
+                            fprintf(stderr, "[sddmm stamps] grid %u x %u, %d working waves; shader clocks per wave: prologue %.0f, wait+barrier %.0f, issue %.0f, reads+products %.0f, "
+                                            "row/column sums %.0f, tile+stores+atomics %.0f, lifetime %.0f (max %.0f), first start to last end %.0f\n",
+                                    grid.x, grid.y, nw, sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[3] / nw, sum[5] / nw, sum[7] / nw, sum[4] / nw, life_max, (double)(tmax - tmin));
                     }
                     sd_done = true;
                     if (first_it) {  // certified by spare workgroups of the next iteration's k_dual_h, or by a launch of its own after the chunk's last
                         fv_pending.plan = eng.plan_d.p; fv_pending.viol = eng.viol_d.p; fv_pending.o2 = eng.partial_o2.p; fv_pending.n_o2 = eng.mf.nb;
-                        fv_pending.u2 = eng.partial_sq.p; fv_pending.du2 = eng.partial_du.p; fv_pending.n_u2 = eng.npart_start; fv_pending.Dpad = Dpad;
+                        fv_pending.u2 = eng.partial_sq.p; fv_pending.du2 = fv_measure ? eng.partial_du.p : nullptr; fv_pending.rows = K; fv_pending.n_u2 = eng.npart_start; fv_pending.Dpad = Dpad;
                         fv_pending.nwg = Dpad / FV_COLS;
                         fv_pending.cA = first_a16_guess ? F16_UNIT : F16_CA_TWO;
                         fv_pending.du_scale = fv_du_scale;
