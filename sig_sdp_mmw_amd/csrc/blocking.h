@@ -84,6 +84,10 @@ struct HostBlocking {
     std::vector<int32_t> m_tepos;       // [listed entries] CSR position of the entry (row -> column) ...
     std::vector<int32_t> m_temir;       // ... and of its mirror (column -> row): X is symmetric, every undirected edge is computed ONCE, by the block of
                                         // the endpoint that comes first in the blocked order, and stored to both positions
+    // X in the SDDMM's own order ("tile order"): slot w of the tile lists holds edge w, the K diagonal entries follow by row id.
+    // m_e2w[e] = slot of CSR entry e (an edge's two entries share one slot; a diagonal entry has slot n_edges + row).
+    std::vector<int32_t> m_e2w;         // [nnz]
+    int64_t m_nedges = 0;               // listed entries = undirected edges
     int m_ntile_max = 0;                // most union tiles any block has to compute (from its first tile with a listed entry)
     double m_reuse = 0.0;
     int nbm() const { return (int)m_rowptr.size() - 1; }
@@ -584,6 +588,8 @@ inline void build_mfma_blocking(HostBlocking& B, int K, const std::vector<int32_
             B.m_trc.assign((size_t)B.m_tptr.back(), 0);
             B.m_tepos.assign((size_t)B.m_tptr.back(), -1);
             B.m_temir.assign((size_t)B.m_tptr.back(), -1);
+            B.m_nedges = B.m_tptr.back();
+            B.m_e2w.assign((size_t)nnz, -1);
             B.m_tmask.assign((size_t)B.m_tbase[nbm] * 64, 0);
         }
         run([&, pass](int b0, int b1) {
@@ -609,6 +615,8 @@ inline void build_mfma_blocking(HostBlocking& B, int K, const std::vector<int32_
                                 const int c = indices[e];
                                 const int32_t* lo = std::lower_bound(indices.data() + indptr[c], indices.data() + indptr[c + 1], r);
                                 B.m_temir[w] = (int32_t)(lo - indices.data());
+                                B.m_e2w[e] = w;
+                                B.m_e2w[B.m_temir[w]] = w;
                             }
                             const int r5 = rl & 31;  // accumulator slot of (row r5, column li & 31): lane = column + 32 ((r5 >> 2) & 1), register (r5 & 3) + 4 (r5 >> 3)
                             B.m_tmask[(size_t)tile * 64 + (li & 31) + 32 * ((r5 >> 2) & 1)] |= (uint16_t)(1u << ((r5 & 3) + 4 * (r5 >> 3)));
@@ -618,6 +626,10 @@ inline void build_mfma_blocking(HostBlocking& B, int K, const std::vector<int32_
                 for (int u = un_ptr[b]; u < un_ptr[b + 1]; ++u) loc2[un_cols[u]] = -1;
             }
         });
+    }
+    for (int k = 0; k < K; ++k) {  // diagonal entries (stored in every row of the L / X pattern)
+        const int32_t* lo = std::lower_bound(indices.data() + indptr[k], indices.data() + indptr[k + 1], k);
+        if (lo != indices.data() + indptr[k + 1] && *lo == k) B.m_e2w[(size_t)(lo - indices.data())] = (int32_t)(B.m_nedges + k);
     }
     B.fits_mfma = true;
 }
@@ -796,6 +808,13 @@ inline std::string verify_mfma_blocking(const HostBlocking& B, int K, const std:
         }
     }
     if (2 * listed != nnz - K) return "the tile lists do not hold every undirected edge once";
+    if (B.m_nedges != listed || (int64_t)B.m_e2w.size() != nnz) return "tile-order slot map has the wrong size";
+    for (int k = 0; k < K; ++k)
+        for (int e = indptr[k]; e < indptr[k + 1]; ++e) {
+            const int w = B.m_e2w[e];
+            if (indices[e] == k) { if (w != B.m_nedges + k) return "diagonal slot is off"; }
+            else if (w < 0 || w >= listed || (B.m_tepos[w] != e && B.m_temir[w] != e)) return "edge slot does not list the entry";
+        }
     return "";
 }
 

@@ -28,6 +28,14 @@ template <typename T> struct PatternDev {
     const T* S_sum;
     const T* inv_norm_H;  // 1/norm_H
     const T* cH;          // h_max/K - S_sum/(K Z)
+    // where X lives.  nullptr / -1: `xval` is CSR-ordered like the pattern.  Otherwise X is in the matrix-core SDDMM's tile order
+    // (kernels_mfma.h): entry e sits in slot e2w[e], the diagonal of row k in slot xdiag_base + k, association pair p in slot xasso[p]
+    const int* e2w = nullptr;
+    const int* xasso = nullptr;
+    int xdiag_base = -1;
+    __device__ __forceinline__ int xslot(int e) const { return e2w ? e2w[e] : e; }
+    __device__ __forceinline__ int xdiag(int k) const { return xdiag_base >= 0 ? xdiag_base + k : diag_pos[k]; }
+    __device__ __forceinline__ int xpair(int p) const { return xasso ? xasso[p] : asso_pos[p]; }
 };
 
 // The sketch of an iteration is pure VALU work that depends on nothing but (seed, iteration): it rides as extra workgroups in
@@ -59,17 +67,17 @@ __global__ __launch_bounds__(BLOCK) void k_dual_rows(PatternDev<T> P, const T* _
         double s = 0.0;
         const int dp = P.diag_pos[row];
         for (int e = P.indptr[row] + lane; e < P.indptr[row + 1]; e += WAVE)
-            if (e != dp) s += (double)xval[e];
+            if (e != dp) s += (double)xval[P.xslot(e)];
         s = wave_sum(s);
         if (lane == 0) {
             rsum[row] = (T)s;
-            e_this[row] = (T)(((double)xval[dp] - 1.0) / (1.0 - invK));  // mmw.py:127
+            e_this[row] = (T)(((double)xval[P.xdiag(row)] - 1.0) / (1.0 - invK));  // mmw.py:127
         }
     }
     const double Zm1 = (double)(P.Z - 1);
     const double den = 1.0 / ((double)K * Zm1) + 0.5;  // mmw.py:131
     for (int p = blockIdx.x * BLOCK + threadIdx.x; p < P.E_asso; p += gridDim.x * BLOCK)
-        e_this[K + p] = (T)(((double)xval[P.asso_pos[p]] + 1.0 / Zm1) / den);
+        e_this[K + p] = (T)(((double)xval[P.xpair(p)] + 1.0 / Zm1) / den);
 }
 
 // ---- DUAL, step 2: eH = (S_T' r (Z-1)/Z - (h - S_sum/Z)) / norm_H ; e_accu += eta e ; block max ----
@@ -182,7 +190,7 @@ __global__ __launch_bounds__(BLOCK) void k_dual_h(PatternDev<T> P, const T* __re
     for (int c = blockIdx.x * BLOCK + threadIdx.x; c < baseH; c += G * BLOCK) {
         T et;
         if (rsfx) {
-            et = c < K ? (T)(((double)xval[P.diag_pos[c]] - 1.0) / (1.0 - invK)) : (T)(((double)xval[P.asso_pos[c - K]] + 1.0 / Zm1) / denF);
+            et = c < K ? (T)(((double)xval[P.xdiag(c)] - 1.0) / (1.0 - invK)) : (T)(((double)xval[P.xpair(c - K)] + 1.0 / Zm1) / denF);
             e_this[c] = et;
         } else et = e_this[c];
         const T a = (T)((double)e_accu[c] + (double)et * eta);
@@ -991,6 +999,24 @@ template <typename T> __global__ __launch_bounds__(BLOCK) void k_copy_state(Copy
         const unsigned* ps = reinterpret_cast<const unsigned*>(c.plan_src);
         unsigned* pd = reinterpret_cast<unsigned*>(c.plan_dst);
         for (int i = threadIdx.x; i < (int)(sizeof(ExpmPlan) / 4); i += BLOCK) pd[i] = ps[i];
+    }
+}
+// X between the pattern's CSR order and the matrix-core SDDMM's tile order (kernels_mfma.h; e2w = slot of every CSR entry).  Both
+// directions are gathers / scatters over the CSR entries: an edge's two entries hold the same value and share a slot.
+template <typename T> __global__ __launch_bounds__(BLOCK) void k_x_tiles_to_csr(size_t nnz, const int* __restrict__ e2w, const T* __restrict__ t0, T* __restrict__ c0,
+                                                                                 const T* __restrict__ t1, T* __restrict__ c1) {
+    for (size_t e = (size_t)blockIdx.x * BLOCK + threadIdx.x; e < nnz; e += (size_t)gridDim.x * BLOCK) {
+        const int w = e2w[e];
+        c0[e] = t0[w];
+        c1[e] = t1[w];
+    }
+}
+template <typename T> __global__ __launch_bounds__(BLOCK) void k_x_csr_to_tiles(size_t nnz, const int* __restrict__ e2w, const T* __restrict__ c0, T* __restrict__ t0,
+                                                                                 const T* __restrict__ c1, T* __restrict__ t1) {
+    for (size_t e = (size_t)blockIdx.x * BLOCK + threadIdx.x; e < nnz; e += (size_t)gridDim.x * BLOCK) {
+        const int w = e2w[e];
+        t0[w] = c0[e];  // (both entries of an edge write the same value)
+        t1[w] = c1[e];
     }
 }
 template <typename T> __global__ __launch_bounds__(BLOCK) void k_accumulate(size_t n, const T* __restrict__ x, T* __restrict__ sum) {

@@ -556,10 +556,13 @@ struct SdMfmaDev {
     const int* tbase;             // [nb+1] first tile of each block
     const int* tptr;              // [tiles+1] entry ranges
     const unsigned short* trc;    // row in tile << 5 | column in tile
-    const int* tepos;             // CSR position of the entry ...
-    const int* temir;             // ... and of its mirror: every undirected edge is computed once and stored twice (blocking.h, m_temir)
     const unsigned short* tmask;  // [tiles][64] accumulator mask of the listed entries (blocking.h, m_tmask)
+    int nedges;                   // listed entries in all = undirected edges of the pattern
 };
+// X leaves this kernel in TILE ORDER: slot w of the tile lists holds edge w (each undirected edge once -- X is symmetric --, so a wave's
+// entries are one contiguous, fully coalesced run), the K diagonal entries follow by row id.  The running sum of X (mmw.py:77) is kept in
+// the same order and updated right here, while the value is in a register.  Everything else reads X through the slot map of the blocking
+// (m_e2w) or asks the handle for the CSR-ordered copy (Solver::x_to_csr).
 constexpr int SDM_GT = 4;   // union tiles per workgroup
 constexpr int SDM_KC = 2;   // k-steps per chunk (a 128-byte line per row: 64 bytes of hi halves, 64 of lo halves)
 template <int MT> constexpr int sdm_rows() { return 32 * MT + 32 * SDM_GT; }
@@ -649,7 +652,7 @@ __global__ __launch_bounds__(BLOCK) void k_first_verify(FirstVerify V) { first_v
 template <int MT>
 __global__ __launch_bounds__(4 * MT * 64)
 void k_sddmm_mfma(MfmaDev M, SdMfmaDev S, int K, int Dpad, const char* __restrict__ Ypl, const float* __restrict__ d,
-                  const double* __restrict__ tr_part, int ntr, const int* __restrict__ diag_pos, float* __restrict__ xval,
+                  const double* __restrict__ tr_part, int ntr, float* __restrict__ xs_val, float* __restrict__ xs_avg, int accumulate,
                   long long* __restrict__ rsfx = nullptr /* [K], zero at launch */, const long long* __restrict__ dfx = nullptr,
                   unsigned long long* __restrict__ stamps = nullptr /* diagnostic runs: 8 shader-clock sums per wave */) {
     // dfx: the row norms as 2^-40 fixed-point totals (SPMM_FIRST) instead of `d`
@@ -771,19 +774,17 @@ void k_sddmm_mfma(MfmaDev M, SdMfmaDev S, int K, int Dpad, const char* __restric
         if (stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_comp += t - tk1; tk1 = t; }
     }
     static_assert(NW * 4096 + 4 * 32 * MT * 4 <= 2 * CHUNK, "tiles and row-sum parts fit into the chunk buffers");
-    // the wave's entry list (CSR position, mirror position, place in the tile) is static: the first 256 entries are requested here, so
-    // that their round trip passes under the reductions, the barriers and the tile's way through LDS
+    // the wave's entry list (place in the tile of every listed entry) is static: the first 256 entries are requested here, so that
+    // their round trip passes under the reductions, the barriers and the tile's way through LDS
     constexpr int EPL = 4;  // entries per lane and round
-    int ep[EPL], em[EPL];
     unsigned rc[EPL];
+    float xa[EPL];
     auto fetch_list = [&](int base) {
 #pragma unroll
         for (int k = 0; k < EPL; ++k) {
             const int w = base + k * 64 + lane;
-            const bool ok = w < tw1;
-            ep[k] = ok ? S.tepos[w] : -1;
-            em[k] = ok ? S.temir[w] : -1;
-            rc[k] = ok ? (unsigned)S.trc[w] : 0u;
+            rc[k] = w < tw1 ? (unsigned)S.trc[w] : 0xFFFFu;
+            xa[k] = (w < tw1 && accumulate) ? xs_avg[w] : 0.f;
         }
     };
     fetch_list(tw0);
@@ -820,10 +821,11 @@ void k_sddmm_mfma(MfmaDev M, SdMfmaDev S, int K, int Dpad, const char* __restric
         if (base != tw0) fetch_list(base);
 #pragma unroll
         for (int k = 0; k < EPL; ++k)
-            if (ep[k] >= 0) {
+            if (rc[k] != 0xFFFFu) {
+                const int w = base + k * 64 + lane;
                 const float x = tile[rc[k]] * inv_tr;
-                xval[ep[k]] = x;
-                xval[em[k]] = x;
+                xs_val[w] = x;
+                if (accumulate) xs_avg[w] = xa[k] + x;
             }
     }
     if (rsfx && lane < 32 && csum != 0.f) {  // (exactly zero where the column has no listed entry in this tile)
@@ -833,7 +835,9 @@ void k_sddmm_mfma(MfmaDev M, SdMfmaDev S, int K, int Dpad, const char* __restric
     if (by == 0)  // the diagonal of the block's rows from the exact row norms
         for (int i = threadIdx.x; i < nrows; i += THREADS) {
             const int row = rows_l[i];
-            xval[diag_pos[row]] = (float)((dfx ? (double)dfx[row] * (1.0 / SDM_FX) : (double)d[row]) / tr);
+            const float x = (float)((dfx ? (double)dfx[row] * (1.0 / SDM_FX) : (double)d[row]) / tr);
+            xs_val[S.nedges + row] = x;
+            if (accumulate) xs_avg[S.nedges + row] += x;
         }
     if (rsfx)
         for (int i = threadIdx.x; i < nrows; i += THREADS) {

@@ -84,7 +84,14 @@ template <typename T> struct Solver final : mmw_solver {
     DevBuf<ExpmPlan> sn_plan;        // plan (with its history) at the start of the pending chunk
     DevBuf<int> b_kbase, b_fpos, b_mdesc, b_munfixed, b_morder;  // matrix-core SpMM: its row blocks, CSR entry -> fragment image position
     DevBuf<unsigned> afrag;          // the matrix as bf16 hi << 16 | lo words in MFMA fragment order
-    DevBuf<int> b_tbase, b_tptr, b_tepos, b_temir;  // matrix-core SDDMM: pattern entries by 32 x 32 output tile
+    DevBuf<int> b_tbase, b_tptr;  // matrix-core SDDMM: pattern entries by 32 x 32 output tile
+    // X in the matrix-core SDDMM's tile order (kernels_mfma.h): xs_val / xs_avg hold X and its running sum while x_tiles is set, the
+    // CSR-ordered xval / xavg otherwise; b_e2w maps a CSR entry to its slot, b_xasso an association pair
+    DevBuf<T> xs_val, xs_avg;
+    DevBuf<int> b_e2w, b_xasso;
+    size_t n_xs = 0;        // slots: undirected edges + K
+    bool x_tiles = false;   // which pair of buffers holds the iterate's X
+    bool sn_tiles = false;  // ... and which the pending chunk's snapshot was taken from
     DevBuf<unsigned short> b_trc, b_tmask, xh_planes;
     DevBuf<long long> rsfx;  // [2K] 2^-40 fixed-point totals: [0, K) row sums of the off-diagonal X, left by the matrix-core SDDMM; [K, 2K) row norms of
                              // y = exp(L/2)R from the first-order product (kernels_mfma.h).  Zeroed by every LOSS pass.
@@ -162,6 +169,7 @@ template <typename T> struct Solver final : mmw_solver {
         P.indptr = d_indptr.p; P.col = d_col.p; P.pid = d_pid.p; P.mirror = d_mirror.p; P.diag_pos = d_diag.p;
         P.asso_pos = d_apos.p; P.sab = d_sab.p; P.sba = d_sba.p; P.h_max = d_h.p; P.S_sum = d_ssum.p;
         P.inv_norm_H = d_invn.p; P.cH = d_cH.p;
+        if (x_tiles) { P.e2w = b_e2w.p; P.xasso = b_xasso.p; P.xdiag_base = (int)HB.m_nedges; }
         return P;
     }
 
@@ -425,8 +433,15 @@ template <typename T> struct Solver final : mmw_solver {
             eng.mf_mt = HB.mfma_mt;
             if (!getenv("MMW_NO_MFMA_SDDMM")) {
                 MMW_TRY(b_tbase.upload(HB.m_tbase, st)); MMW_TRY(b_tptr.upload(HB.m_tptr, st)); MMW_TRY(b_trc.upload(HB.m_trc, st));
-                MMW_TRY(b_tepos.upload(HB.m_tepos, st));
-                MMW_TRY(b_temir.upload(HB.m_temir, st));
+                MMW_TRY(b_e2w.upload(HB.m_e2w, st));
+                {
+                    std::vector<int32_t> xa(H.asso_pos.size());
+                    for (size_t i = 0; i < xa.size(); ++i) xa[i] = HB.m_e2w[(size_t)H.asso_pos[i]];
+                    MMW_TRY(b_xasso.upload(xa, st));
+                }
+                n_xs = (size_t)HB.m_nedges + (size_t)K;
+                MMW_TRY(xs_val.alloc(n_xs));
+                MMW_TRY(xs_avg.alloc(n_xs));
                 MMW_TRY(b_tmask.upload(HB.m_tmask, st));
                 MMW_TRY(rsfx.alloc((size_t)2 * K));
                 sddmm_mfma = true;
@@ -695,7 +710,8 @@ template <typename T> struct Solver final : mmw_solver {
         if (eng.viol_d.p) MMW_TRY(eng.clear_violation());
         MMW_TRY(eng.reset_plan_history(true));
         const size_t nnz = (size_t)H.nnzL(), C = (size_t)H.C();
-        MMW_HIP(hipMemcpyAsync(xavg.p, xval.p, nnz * sizeof(T), hipMemcpyDeviceToDevice, st));
+        if (x_tiles) MMW_HIP(hipMemcpyAsync(xs_avg.p, xs_val.p, n_xs * sizeof(T), hipMemcpyDeviceToDevice, st));
+        else MMW_HIP(hipMemcpyAsync(xavg.p, xval.p, nnz * sizeof(T), hipMemcpyDeviceToDevice, st));
         MMW_HIP(hipMemcpyAsync(yavg.p, Y.p, C * sizeof(T), hipMemcpyDeviceToDevice, st));
         phase_us.clear();
         return MMW_OK;
@@ -722,6 +738,7 @@ template <typename T> struct Solver final : mmw_solver {
         if (afrag16.p) MMW_HIP(hipMemsetAsync(afrag16.p, 0, afrag_n * sizeof(unsigned short), st));
         eng.last_mfma_ok = true;
         lblk_stale = false;
+        x_tiles = false;  // the initial point is written in CSR order; the first matrix-core SDDMM call moves it
         MMW_HIP(hipMemsetAsync(xval.p, 0, nnz * sizeof(T), st));
         MMW_HIP(hipMemsetAsync(xavg.p, 0, nnz * sizeof(T), st));
         MMW_HIP(hipMemsetAsync(e_accu.p, 0, C * sizeof(T), st));
@@ -764,11 +781,37 @@ template <typename T> struct Solver final : mmw_solver {
         return MMW_OK;
     }
 
+    // CSR-ordered copies of X and its running sum for whoever needs them (API reads, the factor, the gap, the kernels of the other SDDMM
+    // forms) while the iterate keeps them in tile order; the tile buffers stay the iterate's
+    int x_csr_view() {
+        if (!x_tiles) return MMW_OK;
+        const size_t nnz = (size_t)H.nnzL();
+        hipLaunchKernelGGL((k_x_tiles_to_csr<T>), dim3(grid_elems(nnz)), dim3(BLOCK), 0, st, nnz, b_e2w.p, xs_val.p, xval.p, xs_avg.p, xavg.p);
+        MMW_HIP(hipGetLastError());
+        return MMW_OK;
+    }
+    int x_to_csr() {
+        MMW_TRY(x_csr_view());
+        x_tiles = false;
+        return MMW_OK;
+    }
+    int x_to_tiles() {
+        if (x_tiles) return MMW_OK;
+        if (!b_e2w.p || n_xs == 0) return fail(MMW_ERR_STATE, "internal: no tile order on this handle");
+        const size_t nnz = (size_t)H.nnzL();
+        hipLaunchKernelGGL((k_x_csr_to_tiles<T>), dim3(grid_elems(nnz)), dim3(BLOCK), 0, st, nnz, b_e2w.p, xval.p, xs_val.p, xavg.p, xs_avg.p);
+        MMW_HIP(hipGetLastError());
+        x_tiles = true;
+        return MMW_OK;
+    }
     int copy_state(bool save) {
         const size_t nnz = (size_t)H.nnzL(), C = (size_t)H.C();
+        if (save) sn_tiles = x_tiles;
+        else x_tiles = sn_tiles;  // the snapshot goes back into the buffers it was taken from
         DevBuf<T>* snap[6] = {&sn_lval, &sn_xval, &sn_xavg, &sn_Y, &sn_yavg, &sn_eaccu};
-        DevBuf<T>* live[6] = {&lval, &xval, &xavg, &Y, &yavg, &e_accu};
-        const size_t len[6] = {nnz, nnz, nnz, C, C, C};
+        DevBuf<T>* live[6] = {&lval, x_tiles ? &xs_val : &xval, x_tiles ? &xs_avg : &xavg, &Y, &yavg, &e_accu};
+        const size_t nx = x_tiles ? n_xs : nnz;
+        const size_t len[6] = {nnz, nx, nx, C, C, C};
         CopySet<T> cs;
         for (int i = 0; i < 6; ++i) {
             if (snap[i]->n < len[i]) MMW_TRY(snap[i]->alloc(len[i]));
@@ -938,7 +981,12 @@ template <typename T> struct Solver final : mmw_solver {
         return MMW_OK;
     }
     int iterate_impl(int32_t n, const double* randv, uint64_t seed, bool optimistic) {
+        // X on the pattern comes from the matrix-core SDDMM in this call (decided below, per iteration, by the same expression): it
+        // writes -- and the DUAL phase then reads -- X in tile order; every other SDDMM form works on the CSR order
+        const bool sd_mf_call = sizeof(T) == 4 && sddmm_mfma && eng.use_blk && eng.method == MMW_EXPM_LANCZOS && (eng.lay.Dpad % 32) == 0 && b_e2w.p != nullptr;
+        if (n > 0) MMW_TRY(sd_mf_call ? x_to_tiles() : x_to_csr());
         const PatternDev<T> P = pat();
+        const T* const xcur = x_tiles ? xs_val.p : xval.p;  // the X the DUAL phase reads (the layout does not change inside a call)
         const int gr = grid_rows(K);
         const int C = (int)H.C();
         const int gc = grid_elems((size_t)C);
@@ -972,7 +1020,7 @@ template <typename T> struct Solver final : mmw_solver {
             const FirstVerify fv = fv_pending;
             fv_pending = FirstVerify{};
             if (rs_it) ++n_rs_iters;
-            if (!rs_it) hipLaunchKernelGGL((k_dual_rows<T>), dim3(gr), dim3(BLOCK), 0, st, P, xval.p, rsum.p, e_this.p);
+            if (!rs_it) hipLaunchKernelGGL((k_dual_rows<T>), dim3(gr), dim3(BLOCK), 0, st, P, xcur, rsum.p, e_this.p);
             // Lagged planning inside a chunk (not the first iteration of a run, a replay or after a change of the iterate, which plan exactly): k_dual_h also takes the row sums of the
             // L it walks over anyway -- last iteration's -- and one extra workgroup of k_softmax_b turns them into this iteration's plan
             // (extrapolated bounds, checked by the next plan): k_rowsums + k_plan leave the critical path.
@@ -991,13 +1039,13 @@ template <typename T> struct Solver final : mmw_solver {
                 if (yun.n < (size_t)C) MMW_TRY(yun.alloc((size_t)C));
                 hipLaunchKernelGGL((k_dual_h<T>), dim3(gr), dim3(BLOCK), 0, st, P, rsum.p, e_this.p, e_accu.p, eta, max_part.p,
                                    (const T*)(lagged_it ? lval.p : nullptr), 0.5, eng.row_part.p, (const double*)(scal.p + 4), yun.p, wH.p, sum_part.p,
-                                   rs_it, (const T*)xval.p);
+                                   rs_it, xcur);
                 hipLaunchKernelGGL(k_dual_scal, dim3(1 + fv.nwg), dim3(DSCAL_THREADS), 0, st, sum_part.p, max_part.p, gr, scal.p,
                                    dual_gap, eng.viol_d.p, fv);
             } else {
                 hipLaunchKernelGGL((k_dual_h<T>), dim3(gr + fv.nwg), dim3(BLOCK), 0, st, P, rsum.p, e_this.p, e_accu.p, eta, max_part.p,
                                    (const T*)(lagged_it ? lval.p : nullptr), 0.5, eng.row_part.p, (const double*)nullptr, (T*)nullptr, (T*)nullptr,
-                                   (double*)nullptr, rs_it, (const T*)xval.p, fv);
+                                   (double*)nullptr, rs_it, xcur, fv);
                 hipLaunchKernelGGL((k_softmax_a<T>), dim3(gc), dim3(BLOCK), 0, st, P, e_accu.p, Y.p, max_part.p, gr, sum_part.p);
                 hipLaunchKernelGGL((k_softmax_b<T>), dim3(gc + (lagged_it ? 1 : 0)), dim3(BLOCK), 0, st, C, Y.p, yavg.p, acc, sum_part.p, gc, scal.p,
                                    K + (int)H.E_asso(), d_invn.p, wH.p, pa, max_part.p, gr);
@@ -1064,7 +1112,7 @@ template <typename T> struct Solver final : mmw_solver {
             if (!sketch_rode) MMW_TRY(kt.end());
             MMW_HIP(hipGetLastError());
             // X on the pattern runs on the matrix cores too when the exponential did: the combination then also writes y's planes
-            const bool sd_mf = sddmm_mfma && eng.use_blk && eng.method == MMW_EXPM_LANCZOS && (Dpad % 32) == 0;
+            const bool sd_mf = sd_mf_call;
             eng.out_planes = nullptr;
             if constexpr (sizeof(T) == 4) {
                 if (sd_mf) {
@@ -1098,7 +1146,7 @@ template <typename T> struct Solver final : mmw_solver {
             if constexpr (sizeof(T) == 4) {
                 if (sd_mf) {
                     SdMfmaDev SM;
-                    SM.tbase = b_tbase.p; SM.tptr = b_tptr.p; SM.trc = b_trc.p; SM.tepos = b_tepos.p; SM.temir = b_temir.p;
+                    SM.tbase = b_tbase.p; SM.tptr = b_tptr.p; SM.trc = b_trc.p; SM.nedges = (int)HB.m_nedges;
                     const long long* dfx = first_it ? rsfx.p + K : nullptr;
                     const double* trp = first_it ? tr1_part.p : tr_part.p;
                     const int ntr = first_it ? ntr1 : gr;
@@ -1116,11 +1164,11 @@ template <typename T> struct Solver final : mmw_solver {
                     if (HB.mfma_mt == 2) {
                         MMW_TRY(set_max_lds(reinterpret_cast<const void*>(&k_sddmm_mfma<2>), sdm_lds_bytes<2>()));
                         hipLaunchKernelGGL((k_sddmm_mfma<2>), grid, dim3(512), sdm_lds_bytes<2>(), st, eng.mf, SM, K, Dpad,
-                                           reinterpret_cast<const char*>(xh_planes.p), drow.p, trp, ntr, d_diag.p, xval.p, rs_out, dfx, sdm_stamps.p);
+                                           reinterpret_cast<const char*>(xh_planes.p), drow.p, trp, ntr, xs_val.p, xs_avg.p, acc, rs_out, dfx, sdm_stamps.p);
                     } else {
                         MMW_TRY(set_max_lds(reinterpret_cast<const void*>(&k_sddmm_mfma<1>), sdm_lds_bytes<1>()));
                         hipLaunchKernelGGL((k_sddmm_mfma<1>), grid, dim3(256), sdm_lds_bytes<1>(), st, eng.mf, SM, K, Dpad,
-                                           reinterpret_cast<const char*>(xh_planes.p), drow.p, trp, ntr, d_diag.p, xval.p, rs_out, dfx, sdm_stamps.p);
+                                           reinterpret_cast<const char*>(xh_planes.p), drow.p, trp, ntr, xs_val.p, xs_avg.p, acc, rs_out, dfx, sdm_stamps.p);
                     }
                     if (want_st) {
                         std::vector<unsigned long long> h(n_st);
@@ -1220,7 +1268,8 @@ template <typename T> struct Solver final : mmw_solver {
                 default: hipLaunchKernelGGL((k_sddmm<T, 4>), dim3(gr), dim3(BLOCK), 0, st, P, Dpad, eng.lay.LPR, eng.lay.G, Xh.p, drow.p, tr_part.p, gr, xval.p, xavg.p, acc); break;
             }
             // the running sum of X (mmw.py:77-78): one coalesced pass; none of the SDDMM kernels read-modify-writes xavg
-            if (acc && it + 1 < n && !kt_exact()) xavg_deferred = true;  // the next iteration's LOSS pass adds it
+            if (sd_done) {  // the matrix-core SDDMM added X to its running sum itself (tile order)
+            } else if (acc && it + 1 < n && !kt_exact()) xavg_deferred = true;  // the next iteration's LOSS pass adds it
             else if (acc) hipLaunchKernelGGL((k_accumulate<T>), dim3((unsigned)std::min<size_t>(((size_t)H.nnzL() + BLOCK - 1) / BLOCK, 4096)), dim3(BLOCK), 0, st, (size_t)H.nnzL(), xval.p, xavg.p);
             MMW_TRY(kt.end());
             MMW_HIP(hipGetLastError());
@@ -1307,8 +1356,8 @@ template <typename T> struct Solver final : mmw_solver {
                 return copy_d2h(out, out64.p, sizeof(double), st);
             }
             case MMW_F_LVAL: return export_T(lval.p, nnz, out, n);
-            case MMW_F_XVAL: return export_T(xval.p, nnz, out, n);
-            case MMW_F_XAVG: return export_T(xavg.p, nnz, out, n);
+            case MMW_F_XVAL: MMW_TRY(x_csr_view()); return export_T(xval.p, nnz, out, n);
+            case MMW_F_XAVG: MMW_TRY(x_csr_view()); return export_T(xavg.p, nnz, out, n);
             case MMW_F_YAVG: return export_T(yavg.p, C, out, n);
             case MMW_F_XHALF: return export_block(Xh.p, out, n);
             case MMW_F_SKETCH: {
@@ -1375,13 +1424,17 @@ template <typename T> struct Solver final : mmw_solver {
         MMW_HIP(hipSetDevice(device));
         MMW_TRY(settle());
         if (iter >= nit) return fail(MMW_ERR_STATE, "mmw_gap: call it before an iteration (the running sums then hold iter+1 terms)");
-        return extras.gap(pat(), d_lrow.p, xavg.p, yavg.p, iter + 1, out);
+        MMW_TRY(x_csr_view());
+        PatternDev<T> Pc = pat();  // the gap's kernels walk the CSR copy
+        Pc.e2w = nullptr; Pc.xasso = nullptr; Pc.xdiag_base = -1;
+        return extras.gap(Pc, d_lrow.p, xavg.p, yavg.p, iter + 1, out);
     }
     int factor(int32_t rank, double* out, uint64_t seed) override {
         if (host_only) return fail(MMW_ERR_STATE, "host-only handle");
         MMW_HIP(hipSetDevice(device));
         MMW_TRY(settle());
         if (iter < nit) return fail(MMW_ERR_STATE, "mmw_factor: run all announced iterations first (the average divides by nit)");
+        MMW_TRY(x_csr_view());
         return extras.factor(d_indptr.p, d_col.p, xavg.p, nit, rank, out, seed);
     }
     int round(int32_t Zr, int32_t Dp, const double* gX, int32_t nbatch, const double* randv, int32_t* z_out, int32_t* rem_out) override {
