@@ -567,7 +567,7 @@ constexpr int SDM_GT = 4;   // union tiles per workgroup
 constexpr int SDM_KC = 2;   // k-steps per chunk (a 128-byte line per row: 64 bytes of hi halves, 64 of lo halves)
 template <int MT> constexpr int sdm_rows() { return 32 * MT + 32 * SDM_GT; }
 template <int MT> constexpr int sdm_chunk_bytes() { return 2 * sdm_rows<MT>() * 32 * SDM_KC; }
-template <int MT> constexpr int sdm_lds_bytes() { return sdm_rows<MT>() * 4 + 2 * sdm_chunk_bytes<MT>(); }
+template <int MT, int NB = 2> constexpr int sdm_lds_bytes() { return sdm_rows<MT>() * 4 + NB * sdm_chunk_bytes<MT>(); }  // NB chunks resident
 
 // The first-order exponential (SPMM_FIRST) is certified after the fact, off the critical path: a few spare workgroups of the next
 // iteration's k_dual_h launch (or k_first_verify at the end of a chunk) fold the column sums of o^2 (the product's slabs), of u^2 and
@@ -649,7 +649,7 @@ __device__ inline void first_verify(const FirstVerify& V, int wg) {
 }
 __global__ __launch_bounds__(BLOCK) void k_first_verify(FirstVerify V) { first_verify(V, (int)blockIdx.x); }
 
-template <int MT>
+template <int MT, int NB = 2>
 __global__ __launch_bounds__(4 * MT * 64)
 void k_sddmm_mfma(MfmaDev M, SdMfmaDev S, int K, int Dpad, const char* __restrict__ Ypl, const float* __restrict__ d,
                   const double* __restrict__ tr_part, int ntr, float* __restrict__ xs_val, float* __restrict__ xs_avg, int accumulate,
@@ -731,7 +731,7 @@ void k_sddmm_mfma(MfmaDev M, SdMfmaDev S, int K, int Dpad, const char* __restric
     }
     const int cw = wv < NP ? (NP - wv + NW - 1) / NW : 0;
     auto issue = [&](int c) {
-        const unsigned dst_l = bufs_l + (unsigned)((c & 1) * CHUNK);
+        const unsigned dst_l = bufs_l + (unsigned)((c % NB) * CHUNK);
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
             if (j < cw) mf_dma16(pbase[j] + (size_t)c * (64 * SDM_KC), dst_l + (unsigned)((wv + NW * j) * 1024));
@@ -752,15 +752,17 @@ void k_sddmm_mfma(MfmaDev M, SdMfmaDev S, int K, int Dpad, const char* __restric
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[v] = 0.f;
     const int NC = Dpad / (16 * SDM_KC);
-    issue(0);
+#pragma unroll
+    for (int c = 0; c < NB - 1; ++c)
+        if (c < NC) issue(c);
     if (stamps) { tk1 = __builtin_amdgcn_s_memtime(); t_pro = tk1 - tk0; }
     for (int c = 0; c < NC; ++c) {
-        mf_wait_vmcnt(0);              // two buffers: chunk c is the only one outstanding here
-        __builtin_amdgcn_s_barrier();  // chunk c landed for everyone; everyone left the other buffer
+        mf_wait_vmcnt(cw * min(NC - 1 - c, NB - 2));  // this wave's pieces of chunk c have landed: at most the younger chunks' are outstanding
+        __builtin_amdgcn_s_barrier();  // chunk c landed for everyone; everyone left the buffer of chunk c - 1
         if (stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_wait += t - tk1; tk1 = t; }
-        if (c + 1 < NC) issue(c + 1);
+        if (c + NB - 1 < NC) issue(c + NB - 1);
         if (stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_issue += t - tk1; tk1 = t; }
-        const char* cb = bufs + (c & 1) * CHUNK;
+        const char* cb = bufs + (c % NB) * CHUNK;
 #pragma unroll
         for (int kk = 0; kk < SDM_KC; ++kk) {
             const uint4 ah = *reinterpret_cast<const uint4*>(cb + offA[kk][0]);
@@ -773,7 +775,7 @@ void k_sddmm_mfma(MfmaDev M, SdMfmaDev S, int K, int Dpad, const char* __restric
         }
         if (stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_comp += t - tk1; tk1 = t; }
     }
-    static_assert(NW * 4096 + 4 * 32 * MT * 4 <= 2 * CHUNK, "tiles and row-sum parts fit into the chunk buffers");
+    static_assert(NW * 4096 + 4 * 32 * MT * 4 <= NB * CHUNK, "tiles and row-sum parts fit into the chunk buffers");
     // the wave's entry list (place in the tile of every listed entry) is static: the first 256 entries are requested here, so that
     // their round trip passes under the reductions, the barriers and the tile's way through LDS
     constexpr int EPL = 4;  // entries per lane and round

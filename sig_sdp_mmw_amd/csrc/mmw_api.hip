@@ -1161,15 +1161,16 @@ template <typename T> struct Solver final : mmw_solver {
                         MMW_TRY(sdm_stamps.alloc(n_st));
                         MMW_HIP(hipMemsetAsync(sdm_stamps.p, 0, n_st * sizeof(unsigned long long), st));
                     }
-                    if (HB.mfma_mt == 2) {
-                        MMW_TRY(set_max_lds(reinterpret_cast<const void*>(&k_sddmm_mfma<2>), sdm_lds_bytes<2>()));
-                        hipLaunchKernelGGL((k_sddmm_mfma<2>), grid, dim3(512), sdm_lds_bytes<2>(), st, eng.mf, SM, K, Dpad,
-                                           reinterpret_cast<const char*>(xh_planes.p), drow.p, trp, ntr, xs_val.p, xs_avg.p, acc, rs_out, dfx, sdm_stamps.p);
-                    } else {
-                        MMW_TRY(set_max_lds(reinterpret_cast<const void*>(&k_sddmm_mfma<1>), sdm_lds_bytes<1>()));
-                        hipLaunchKernelGGL((k_sddmm_mfma<1>), grid, dim3(256), sdm_lds_bytes<1>(), st, eng.mf, SM, K, Dpad,
-                                           reinterpret_cast<const char*>(xh_planes.p), drow.p, trp, ntr, xs_val.p, xs_avg.p, acc, rs_out, dfx, sdm_stamps.p);
-                    }
+                    static const int sd_nb = getenv("MMW_SD_NB") ? atoi(getenv("MMW_SD_NB")) : 2;  // chunks resident per workgroup (3: measured 1 % slower)
+#define MMW_SDM_LAUNCH(MT, NB)                                                                                                               \
+    do {                                                                                                                                     \
+        MMW_TRY(set_max_lds(reinterpret_cast<const void*>(&k_sddmm_mfma<MT, NB>), sdm_lds_bytes<MT, NB>()));                                 \
+        hipLaunchKernelGGL((k_sddmm_mfma<MT, NB>), grid, dim3(256 * MT), (sdm_lds_bytes<MT, NB>()), st, eng.mf, SM, K, Dpad,                 \
+                           reinterpret_cast<const char*>(xh_planes.p), drow.p, trp, ntr, xs_val.p, xs_avg.p, acc, rs_out, dfx, sdm_stamps.p); \
+    } while (0)
+                    if (HB.mfma_mt == 2) { if (sd_nb == 3) MMW_SDM_LAUNCH(2, 3); else MMW_SDM_LAUNCH(2, 2); }
+                    else { if (sd_nb == 3) MMW_SDM_LAUNCH(1, 3); else MMW_SDM_LAUNCH(1, 2); }
+#undef MMW_SDM_LAUNCH
                     if (want_st) {
                         std::vector<unsigned long long> h(n_st);
                         MMW_HIP(hipMemcpyAsync(h.data(), sdm_stamps.p, n_st * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
