@@ -136,7 +136,7 @@ def spawn_ranks(n, cmd, env=None, timeout=None):
     return rc, out0
 
 
-def coloring_block(state, dtype_name, nit, eta, warm, geometry=None, speculate=False):
+def coloring_block(state, dtype_name, nit, eta, warm, geometry=None, speculate=False, device_state=False):
     """Wall-clock of the whole binary search (binary_search_relaxation.run) to a feasible colouring, with the device-RNG /
     batched-rounding fast path of the drop-in class (the flow of sim_script/journal_version/sim_mmw_time.py:30-36)."""
     from sig_sdp_mmw_amd.binary_search import binary_search_relaxation
@@ -147,9 +147,17 @@ def coloring_block(state, dtype_name, nit, eta, warm, geometry=None, speculate=F
     alg = mmw(nit=nit, eta=eta, dtype=dtype_name, rng="device", seed=1, warm_start=warm)
     bs.feasibility_check_alg = alg
     np.random.seed(0)
+    env0 = None
+    if device_state:  # the state stays where the device generator made it (mmw_create_from_env): no host CSR, no host pattern build
+        from sig_sdp_mmw_amd import _lib
+        from sig_sdp_mmw_amd.graphs import min_sinr_dec, _NOISE_FLOOR_DBM
+        env0 = _lib.DeviceEnv(geometry["sta_locs"], geometry["ap_locs"], min_sinr=min_sinr_dec(), noise_floor_dbm=_NOISE_FLOOR_DBM)
+        state = env0.device_state()
     t0 = time.perf_counter()
     z_vec, Z, rem = bs.run(state)
     wall = time.perf_counter() - t0
+    if env0 is not None:
+        env0.close()
     per = bs.LOGGED_NP_DATA["bs_search_per_it"]
     lg = alg.LOGGED_NP_DATA
     alg.close()
@@ -170,7 +178,7 @@ def coloring_block(state, dtype_name, nit, eta, warm, geometry=None, speculate=F
             "semantics": ("warm-started probes (opt-in, NOT the reference's search): later probes continue from the previous probe's iterate and run "
                           "ceil(nit/3) iterations" if warm else
                           "reference: every probe restarts from Y = 1/C, X = I and runs nit iterations (mmw.py:62-68)"),
-            "score": score,
+            "score": score, "state": "device-resident (mmw_create_from_env)" if device_state else "host CSR (mmw_create)",
             "warm_start": bool(warm), "mids": [int(x) for x in per[:, 5]], "rems": [int(x) for x in per[:, 7]],
             "iterations": its,
             "speculation": ({"probes_solved_ahead_and_dropped": int(bs.LOGGED_NP_DATA["bs_speculation"][0, 4])}
@@ -488,8 +496,11 @@ def main():
             s.close()
         # reference semantics first (cold probes): THE colouring figure; the warm-started search is an opt-in variant, labelled as such
         out["coloring"] = coloring_block(state, dtype_name, args.coloring_nit, args.eta, warm=False, geometry=geometry0, speculate=args.coloring_speculate)
+        if geometry0 is not None:  # the same search with the state handed over on the device (f2): no host round trip of S / Q, no host pattern build
+            out["coloring_device_state"] = coloring_block(state, dtype_name, args.coloring_nit, args.eta, warm=False, geometry=geometry0, device_state=True)
         if not args.no_coloring_warm:
-            out["coloring_warm_start"] = coloring_block(state, dtype_name, args.coloring_nit, args.eta, warm=True, geometry=geometry0)
+            out["coloring_warm_start"] = coloring_block(state, dtype_name, args.coloring_nit, args.eta, warm=True, geometry=geometry0,
+                                                        device_state=geometry0 is not None)
 
     # ---- CPU baseline: the oracle on this host, bounded sample of the same instance (rank 0, N = 1 only)
     if rank == 0 and world == 1 and args.cpu_iters != 0:

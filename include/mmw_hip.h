@@ -223,6 +223,21 @@ int mmw_env_state(mmw_env* e, int32_t* S_indptr, int32_t* S_indices, double* S_d
                   double* Q_data, double* h_max);
 int mmw_env_evaluate(mmw_env* e, const double* z_vec, int32_t Z, double packet_bit, double bandwidth, double slot_time,
                      double* sinr_out, double* bler_out);
+/*
+ * mmw_create_from_env: mmw_create for the state this generator holds, WITHOUT the host round trip (env.generate_S_Q_hmax ->
+ * mmw._process_state, sim_src/env/env.py:168-196 -> sim_src/alg/mmw.py:26-57): the transpose S_T', the association mask, the symmetric
+ * pattern of L / X with its per-entry weights, mirrors and pair ids, the edge lists and the row statistics are built by device
+ * kernels straight from the generator's receive powers (csrc/pattern_device.h; rows come out sorted, no sort and no atomic), and the
+ * rounding's view of the state from its CSR of S_gain.  The handle is the one mmw_create makes from mmw_env_state's arrays: same
+ * pattern, same lists (every mmw_read_i32 field equal), S_sum / norm_H / ST_DATA bit-identical.  Only the traversal order of the
+ * locality blocking differs: the generator knows the stations' coordinates, so the row blocks are runs of a spatial order instead
+ * of patches grown along an RCM order of the pattern (products agree to rounding, not bit for bit; MMW_ENV_RCM=1 forces the latter).
+ * The handle does not keep a reference to `env` after the call returns.
+ * mmw_env_bounds: the bisection's bounds of binary_search_relaxation.py:13-29 for this state, out = {lower, upper}, from the same
+ * count pass (no host matrices).
+ */
+int mmw_create_from_env(mmw_solver** out, mmw_env* env, int dtype, int32_t Z, int32_t rank_radio, double eta, int32_t nit);
+int mmw_env_bounds(mmw_env* e, int32_t out[2]);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,7 @@ I_L_INDPTR, I_L_INDICES, I_ST_INDPTR, I_ST_INDICES, I_GAIN_X, I_GAIN_Y, I_ASSO_X
 EXPORTS = ["mmw_last_error", "mmw_version", "mmw_device_count", "mmw_create", "mmw_destroy", "mmw_sizes", "mmw_set_expm",
            "mmw_set_timing", "mmw_set_profile", "mmw_bench_spmm", "mmw_reset", "mmw_set_slots", "mmw_set_slots_warm", "mmw_set_eta", "mmw_iterate", "mmw_sync", "mmw_sketch", "mmw_read_f64", "mmw_read_i32", "mmw_gap",
            "mmw_factor", "mmw_expm_apply", "mmw_sym_eig", "mmw_round", "mmw_env_create", "mmw_env_destroy", "mmw_env_sizes", "mmw_env_state",
-           "mmw_env_evaluate"]
+           "mmw_env_evaluate", "mmw_create_from_env", "mmw_env_bounds"]
 
 
 class MMWError(RuntimeError):
@@ -77,6 +77,8 @@ def lib():
     L.mmw_env_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     L.mmw_env_state.argtypes = [C.c_void_p, p_i32, p_i32, p_f64, p_i32, p_i32, p_f64, p_f64]
     L.mmw_env_evaluate.argtypes = [C.c_void_p, p_f64, C.c_int32, C.c_double, C.c_double, C.c_double, p_f64, p_f64]
+    L.mmw_create_from_env.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.c_double, C.c_int32]
+    L.mmw_env_bounds.argtypes = [C.c_void_p, p_i32]
     for name in EXPORTS:
         if name not in ("mmw_last_error",):
             getattr(L, name).restype = C.c_int
@@ -141,6 +143,20 @@ class Solver:
         self.dtype = dtype
         self._timing = False
         self._timed = 0
+
+    @classmethod
+    def from_env(cls, env, Z, nit, eta, rank_radio=2, dtype=F64):
+        """The handle for the state a DeviceEnv holds, built on the device without the host round trip (mmw_create_from_env)."""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        check(lib().mmw_create_from_env(C.byref(self._h), env._h, int(dtype), int(Z), int(rank_radio), float(eta), int(nit)))
+        sz = (C.c_int64 * 10)()
+        check(lib().mmw_sizes(self._h, sz))
+        (self.K, self.Z, self.D, self.Dpad, self.nnzL, self.nnzST, self.E_gain, self.E_asso, self.C, _) = [int(x) for x in sz]
+        self.dtype = dtype
+        self._timing = False
+        self._timed = 0
+        return self
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -320,6 +336,17 @@ class DeviceEnv:
         Q = scipy.sparse.csr_matrix((qx, qi, qp), shape=(self.K, self.K))
         return S, Q, h
 
+    def bounds(self):
+        """(lower, upper) slot-count bounds of binary_search_relaxation.py:13-29 for this state, from the device's count pass."""
+        out = np.zeros(2, dtype=np.int32)
+        check(lib().mmw_env_bounds(self._h, _pi(out)))
+        return int(out[0]), int(out[1])
+
+    def device_state(self):
+        """The `state` to hand to the solver classes: behaves like the (S_gain, Q_asso, h_max) tuple (materialised on the host only if
+        someone indexes it), and lets `mmw` / `binary_search_relaxation` stay on the device (Solver.from_env, bounds())."""
+        return DeviceState(self)
+
     def evaluate(self, z, Z, packet_bit=800, bandwidth=5e6, slot_time=1.25e-4, bler=True):
         """(sinr, bler) per user under the colouring z (env.evaluate_sinr / evaluate_bler)."""
         zz = _f64(z)
@@ -341,6 +368,29 @@ class DeviceEnv:
             self.close()
         except Exception:
             pass
+
+
+class DeviceState:
+    """`state` of a DeviceEnv: a lazy (S_gain, Q_asso, h_max) triple that remembers where it lives."""
+
+    def __init__(self, env):
+        self.env = env
+        self.K = env.K
+        self._host = None
+
+    def host(self):
+        if self._host is None:
+            self._host = self.env.state()
+        return self._host
+
+    def __getitem__(self, i):
+        return self.host()[i]
+
+    def __iter__(self):
+        return iter(self.host())
+
+    def __len__(self):
+        return 3
 
 
 def sym_eig(G, rel_tol=1e-13, max_sweeps=30, device=0):

@@ -25,6 +25,8 @@ class binary_search_relaxation(STATS_OBJECT):
         self.speculate = False
 
     def set_bounds(self, state):
+        if hasattr(state, "env") and hasattr(state.env, "bounds") and not (self.force_lower_bound or self.force_full_bound):
+            return state.env.bounds()  # a device-resident state (_lib.DeviceState): the same bounds from the device's count pass
         S, Q = state[0], state[1]
         if self.force_lower_bound:
             lb = int(np.max(np.diff(Q.indptr))) + 1

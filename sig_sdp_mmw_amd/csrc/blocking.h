@@ -71,7 +71,9 @@ struct HostBlocking {
     // The matrix-core kernel has no per-entry LDS budget, so it runs on row blocks of its own: up to 64 rows grown the same
     // way (fewer, larger patches: each staged union row serves ~2x the nonzeros).  m_* mirror order / blk_rowptr / desc / un_fixed.
     std::vector<int32_t> m_order, m_rowptr, m_desc, m_unfixed;
-    std::vector<int32_t> rcm_cache;     // the RCM order both blockings start from
+    std::vector<int32_t> rcm_cache;     // the order both blockings start from: RCM of the pattern, or an order the caller knows to be local
+    bool grow = true;                   // false: blocks are consecutive runs of that order (a spatial order of a geometric graph needs no growing:
+                                        // boustrophedon strips give 21.8 nonzeros per staged row at the benchmark instance, RCM + growing 20.0)
     // matrix-core SDDMM (k_sddmm_mfma): a block's rows x union product comes out in 32 x 32 tiles (row tile, union tile); the
     // off-diagonal pattern entries of every tile, as (row in tile << 5 | column in tile) and CSR position.
     // Tile index = m_tbase[b] + union tile * row tiles + row tile.  A block's union is sorted by blocked position, so the columns
@@ -180,7 +182,7 @@ inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& i
     // two-dimensional patches instead of slices of the one-dimensional RCM order: ~25 % smaller unions for the same rows,
     // i.e. fewer bytes gathered into LDS per nonzero (the gathers run at the CU's L2 rate).
     // MMW_BLK_GROW=0 keeps consecutive RCM rows.
-    const bool grow = !(getenv("MMW_BLK_GROW") && atoi(getenv("MMW_BLK_GROW")) == 0);
+    const bool grow = B.grow && !(getenv("MMW_BLK_GROW") && atoi(getenv("MMW_BLK_GROW")) == 0);
     B.order.assign(K, -1);  // filled block by block: position -> original row
     std::vector<char> assigned(K, 0);
     std::vector<int32_t> in_union(K, 0), in_stamp(K, -1);  // neighbours of v inside the current union (valid for stamp == blk)
@@ -302,7 +304,7 @@ inline void build_blocking(HostBlocking& B, int K, const std::vector<int32_t>& i
     // The blocks are independent here: a few host threads take contiguous runs of blocks, first to count every row's chunks
     // (positions follow from a prefix sum), then to fill.
     const int nbk = B.nb();
-    const int nthreads = std::max(1, std::min({4, nbk, (int)std::thread::hardware_concurrency()}));
+    const int nthreads = std::max(1, std::min({8, nbk, (int)std::thread::hardware_concurrency()}));
     std::vector<int> cut(nthreads + 1, nbk);
     cut[0] = 0;
     for (int t = 1; t < nthreads; ++t) {  // equal shares of the rows
@@ -504,22 +506,28 @@ inline void build_mfma_blocking(HostBlocking& B, int K, const std::vector<int32_
                 if (stamp[c] != blk) {
                     stamp[c] = blk;
                     cur.push_back(c);
-                    for (int f = indptr[c]; f < indptr[c + 1]; ++f) {
-                        const int v = indices[f];
-                        if (in_stamp[v] != blk) { in_stamp[v] = blk; in_union[v] = 0; }
-                        ++in_union[v];
-                    }
+                    if (B.grow)
+                        for (int f = indptr[c]; f < indptr[c + 1]; ++f) {
+                            const int v = indices[f];
+                            if (in_stamp[v] != blk) { in_stamp[v] = blk; in_union[v] = 0; }
+                            ++in_union[v];
+                        }
                 }
             }
             assigned[r] = 1;
             B.m_order[p++] = r;
             ++rows;
             int best = -1, best_fresh = INT32_MAX;
-            for (int c : cur)
-                if (!assigned[c]) {
-                    const int fr = (indptr[c + 1] - indptr[c]) - (in_stamp[c] == blk ? in_union[c] : 0);
-                    if (fr < best_fresh || (fr == best_fresh && rank[c] < rank[best])) { best_fresh = fr; best = c; }
-                }
+            if (B.grow) {
+                for (int c : cur)
+                    if (!assigned[c]) {
+                        const int fr = (indptr[c + 1] - indptr[c]) - (in_stamp[c] == blk ? in_union[c] : 0);
+                        if (fr < best_fresh || (fr == best_fresh && rank[c] < rank[best])) { best_fresh = fr; best = c; }
+                    }
+            } else {  // the next row of the given order
+                while (seed_pos < K && assigned[rcm[seed_pos]]) ++seed_pos;
+                best = seed_pos < K ? rcm[seed_pos] : -1;
+            }
             if (best < 0) break;
             r = best;
         }
@@ -556,7 +564,7 @@ inline void build_mfma_blocking(HostBlocking& B, int K, const std::vector<int32_
     const int MT = B.mfma_mt;
     B.fpos.assign(nnz, -1);
     // the blocks are independent from here on: contiguous runs of them on a few host threads
-    const int nthreads = std::max(1, std::min({4, nbm, (int)std::thread::hardware_concurrency()}));
+    const int nthreads = std::max(1, std::min({8, nbm, (int)std::thread::hardware_concurrency()}));
     std::vector<int> cut(nthreads + 1, nbm);
     cut[0] = 0;
     for (int t = 1; t < nthreads; ++t) {

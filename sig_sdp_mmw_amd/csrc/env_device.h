@@ -18,6 +18,7 @@
 #include <cstring>
 
 #include "device_utils.h"
+#include "pattern_device.h"
 #include "runtime.h"
 
 namespace mmw {
@@ -220,6 +221,44 @@ struct EnvDevice {
     DevBuf<int> asso, ap_cnt, ap_ptr, ap_mem, s_len, q_len, s_ptr, q_ptr, s_idx, q_idx, sl_cnt, sl_ptr, sl_mem;
     int64_t nnzS = 0, nnzQ = 0;
     std::vector<int32_t> h_sptr, h_qptr;
+    // what a solver handle created straight from this generator needs (mmw_create_from_env, pattern_device.h): the transposed receive
+    // powers, every user's position in its AP's member list, the per-row counts of the L / S_T' / edge lists (device and host copies),
+    // and the station coordinates on the host (the row blocks of such a handle follow a spatial order)
+    DevBuf<double> rxT;
+    DevBuf<int> appos, cnt6;          // cnt6: [6][K] = nL, nST, nGU, nQU, sdiag, nSym (k_pat_count)
+    std::vector<int32_t> h_cnt6;
+    std::vector<double> h_sta;
+    bool pat_ready = false;
+    int pattern_inputs() {
+        if (pat_ready) return MMW_OK;
+        MMW_HIP(hipSetDevice(device));
+        MMW_TRY(rxT.alloc((size_t)A * K));
+        MMW_TRY(appos.alloc(K));
+        MMW_TRY(cnt6.alloc((size_t)6 * K));
+        hipLaunchKernelGGL(k_pat_transpose, dim3((K + 31) / 32, (A + 31) / 32), dim3(256), 0, st, K, A, rx.p, rxT.p);
+        hipLaunchKernelGGL(k_pat_appos, dim3(grid_rows(A)), dim3(BLOCK), 0, st, A, ap_ptr.p, ap_mem.p, appos.p);
+        int* c = cnt6.p;
+        hipLaunchKernelGGL(k_pat_count, dim3(grid_rows(K)), dim3(BLOCK), 0, st, K, A, P.thr, rx.p, rxT.p, asso.p, ap_cnt.p, appos.p, c, c + K, c + 2 * (size_t)K,
+                           c + 3 * (size_t)K, c + 4 * (size_t)K, c + 5 * (size_t)K);
+        MMW_HIP(hipGetLastError());
+        h_cnt6.resize((size_t)6 * K);
+        MMW_TRY(copy_d2h(h_cnt6.data(), cnt6.p, h_cnt6.size() * sizeof(int32_t), st));
+        pat_ready = true;
+        return MMW_OK;
+    }
+    // the bisection's bounds (binary_search_relaxation.py:13-29) without the host matrices: lower = most users of one AP, upper = longest
+    // stored off-diagonal row of S + S^T, + 2 (setdiag(0) leaves a stored entry: see binary_search.py)
+    int bounds(int32_t out[2]) {
+        MMW_TRY(pattern_inputs());
+        int lb = 0, ub = 0;
+        for (int k = 0; k < K; ++k) {
+            lb = std::max(lb, h_qptr[k + 1] - h_qptr[k]);
+            ub = std::max(ub, h_cnt6[(size_t)5 * K + k]);
+        }
+        out[0] = lb + 1;
+        out[1] = ub + 2;
+        return MMW_OK;
+    }
 
     ~EnvDevice() {
         if (st) {
@@ -242,6 +281,7 @@ struct EnvDevice {
         MMW_HIP(hipSetDevice(device));
         MMW_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         std::vector<double> hs(sta_xy, sta_xy + 2 * (size_t)K), ha(ap_xy, ap_xy + 2 * (size_t)A);
+        h_sta = hs;
         MMW_TRY(sta.upload(hs, st));
         MMW_TRY(ap.upload(ha, st));
         MMW_TRY(rx.alloc((size_t)K * A));

@@ -1019,6 +1019,9 @@ template <typename T> __global__ __launch_bounds__(BLOCK) void k_x_csr_to_tiles(
         t1[w] = c1[e];
     }
 }
+__global__ __launch_bounds__(BLOCK) void k_gather_idx(size_t n, const int* __restrict__ idx, const int* __restrict__ src, int* __restrict__ dst) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) dst[i] = src[idx[i]];
+}
 template <typename T> __global__ __launch_bounds__(BLOCK) void k_accumulate(size_t n, const T* __restrict__ x, T* __restrict__ sum) {
     for (size_t o = (size_t)blockIdx.x * BLOCK + threadIdx.x; o < n; o += (size_t)gridDim.x * BLOCK) sum[o] += x[o];
 }

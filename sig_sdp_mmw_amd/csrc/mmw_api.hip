@@ -12,11 +12,15 @@
 #include "expm_engine.h"
 #include "kernels_loop.h"
 #include "pattern.h"
+#include "pattern_device.h"
 #include "runtime.h"
 #include "solver_extras.h"
 
 using namespace mmw;
 
+struct mmw_env {
+    mmw::EnvDevice e;
+};
 struct mmw_solver {
     virtual ~mmw_solver() {}
     virtual int sizes(int64_t out[10]) = 0;
@@ -269,6 +273,173 @@ template <typename T> struct Solver final : mmw_solver {
         for (int k = 0; k < K; ++k) invn[k] = 1.0 / H.norm_H[k];
         MMW_TRY(d_invn.upload_cast(invn, st));
         MMW_TRY(d_cH.upload_cast(H.cH, st));
+        return init_common(t_0, t_1, t_struct, /*env=*/nullptr);
+    }
+
+    // ---- mmw_create_from_env: the state never leaves the device.  The generator's receive powers are turned into the pattern, its
+    // per-entry arrays, the edge lists and the row statistics by the kernels of pattern_device.h; the host gets the row pointers (from
+    // the count pass's prefix sums), the column indices (the blockings read them) and three K-vectors.  The lists that only the
+    // API's read fields hand out stay on the device until asked for (ensure_host_lists).
+    struct EnvLists {  // device copies kept for ensure_host_lists
+        DevBuf<int> st_ptr, st_idx, gain_x, gain_y, asso_x, asso_y, gu_ptr, qu_ptr, so_ptr;
+        DevBuf<double> st_val, s_sum, sq_sum;
+        bool host_done = true;  // false: H's list vectors are still empty
+    } envl;
+    int ensure_host_lists() {
+        if (envl.host_done) return MMW_OK;
+        MMW_HIP(hipSetDevice(device));
+        const size_t nst = (size_t)H.n_st, ng = (size_t)H.n_gain, na = (size_t)H.n_asso;
+        H.st_indices.resize(nst); H.st_data.resize(nst);
+        H.gain_x.resize(ng); H.gain_y.resize(ng); H.asso_x.resize(na); H.asso_y.resize(na);
+        H.diag_pos.resize(K); H.asso_pos.resize(na);
+        MMW_TRY(copy_d2h(H.st_indices.data(), envl.st_idx.p, nst * sizeof(int32_t), st));
+        MMW_TRY(copy_d2h(H.st_data.data(), envl.st_val.p, nst * sizeof(double), st));
+        MMW_TRY(copy_d2h(H.gain_x.data(), envl.gain_x.p, ng * sizeof(int32_t), st));
+        MMW_TRY(copy_d2h(H.gain_y.data(), envl.gain_y.p, ng * sizeof(int32_t), st));
+        MMW_TRY(copy_d2h(H.asso_x.data(), envl.asso_x.p, na * sizeof(int32_t), st));
+        MMW_TRY(copy_d2h(H.asso_y.data(), envl.asso_y.p, na * sizeof(int32_t), st));
+        MMW_TRY(copy_d2h(H.diag_pos.data(), d_diag.p, (size_t)K * sizeof(int32_t), st));
+        MMW_TRY(copy_d2h(H.asso_pos.data(), d_apos.p, na * sizeof(int32_t), st));
+        envl.host_done = true;
+        return MMW_OK;
+    }
+    // Row order of a geometric instance: boustrophedon strips about one block wide (blocking.h: consecutive runs of it are compact patches)
+    static std::vector<int32_t> spatial_order(int K, const std::vector<double>& xy, int rows_per_block) {
+        double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+        for (int k = 0; k < K; ++k) {
+            x0 = std::min(x0, xy[2 * k]); x1 = std::max(x1, xy[2 * k]);
+            y0 = std::min(y0, xy[2 * k + 1]); y1 = std::max(y1, xy[2 * k + 1]);
+        }
+        const double area = std::max((x1 - x0) * (y1 - y0), 1e-300);
+        const double w = std::max(std::sqrt(area * (double)rows_per_block / (double)std::max(K, 1)) * 0.9, 1e-300);  // a block is ~ w x w
+        std::vector<std::pair<std::pair<int64_t, double>, int32_t>> key(K);
+        for (int k = 0; k < K; ++k) {
+            const int64_t strip = (int64_t)((xy[2 * k] - x0) / w);
+            key[k] = {{strip, (strip & 1) ? -xy[2 * k + 1] : xy[2 * k + 1]}, k};
+        }
+        std::sort(key.begin(), key.end());
+        std::vector<int32_t> ord(K);
+        for (int k = 0; k < K; ++k) ord[k] = key[k].second;
+        return ord;
+    }
+    EnvDevice* env_src = nullptr;  // during init_env only
+    int init_env(int dev, EnvDevice& E, int32_t Z_, int32_t rr, double eta_, int32_t nit_) {
+        device = dev;
+        auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t_0 = tnow();
+        if (Z_ < 2) return fail(MMW_ERR_ARG, "mmw_create_from_env: Z must be >= 2 (the constraints divide by Z-1)");
+        if (E.K < 2) return fail(MMW_ERR_ARG, "mmw_create_from_env: K must be >= 2");
+        MMW_HIP(hipSetDevice(device));
+        MMW_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        MMW_TRY(E.pattern_inputs());  // (cached in the generator: rxT, positions in the AP lists, the count pass)
+        K = E.K; Z = Z_; rank_radio = rr; eta = eta_; nit = nit_;
+        D = Z * rank_radio;
+        H.K = K; H.Z = Z;
+        const int A = E.A;
+        const int32_t* c6 = E.h_cnt6.data();
+        // prefix sums of the count pass
+        std::vector<int32_t> st_ptr(K + 1, 0), gu_ptr(K + 1, 0), qu_ptr(K + 1, 0), so_ptr(K + 1, 0);
+        H.l_indptr.assign(K + 1, 0);
+        int maxdeg = 1, maxq = 1;
+        for (int k = 0; k < K; ++k) {
+            H.l_indptr[k + 1] = H.l_indptr[k] + c6[k];
+            st_ptr[k + 1] = st_ptr[k] + c6[(size_t)K + k];
+            gu_ptr[k + 1] = gu_ptr[k] + c6[(size_t)2 * K + k];
+            qu_ptr[k + 1] = qu_ptr[k] + c6[(size_t)3 * K + k];
+            const int so_len = (E.h_sptr[k + 1] - E.h_sptr[k]) - c6[(size_t)4 * K + k];
+            so_ptr[k + 1] = so_ptr[k] + so_len;
+            maxdeg = std::max(maxdeg, so_len);
+            maxq = std::max(maxq, E.h_qptr[k + 1] - E.h_qptr[k]);
+            if ((int64_t)H.l_indptr[k] + c6[k] > (int64_t)INT32_MAX) return fail(MMW_ERR_ARG, "mmw_create_from_env: pattern too large for int32 indexing");
+        }
+        env_maxdeg = maxdeg; env_maxq = maxq;
+        const size_t nnz = (size_t)H.l_indptr[K], nst = (size_t)st_ptr[K], ng = (size_t)gu_ptr[K], na = (size_t)qu_ptr[K];
+        H.n_st = (int64_t)nst; H.n_gain = (int64_t)ng; H.n_asso = (int64_t)na;
+        H.st_indptr = st_ptr;
+        MMW_TRY(d_indptr.upload(H.l_indptr, st));
+        MMW_TRY(envl.st_ptr.upload(st_ptr, st)); MMW_TRY(envl.gu_ptr.upload(gu_ptr, st)); MMW_TRY(envl.qu_ptr.upload(qu_ptr, st)); MMW_TRY(envl.so_ptr.upload(so_ptr, st));
+        MMW_TRY(d_col.alloc(nnz)); MMW_TRY(d_lrow.alloc(nnz)); MMW_TRY(d_sab.alloc(nnz)); MMW_TRY(d_sba.alloc(nnz)); MMW_TRY(d_pid.alloc(nnz)); MMW_TRY(d_mirror.alloc(nnz));
+        MMW_TRY(d_diag.alloc(K)); MMW_TRY(d_apos.alloc(na));
+        MMW_TRY(envl.st_idx.alloc(nst)); MMW_TRY(envl.st_val.alloc(nst));
+        MMW_TRY(envl.gain_x.alloc(ng)); MMW_TRY(envl.gain_y.alloc(ng)); MMW_TRY(envl.asso_x.alloc(na)); MMW_TRY(envl.asso_y.alloc(na));
+        MMW_TRY(envl.s_sum.alloc(K)); MMW_TRY(envl.sq_sum.alloc(K));
+        PatOut<T> O;
+        O.l_ptr = d_indptr.p; O.st_ptr = envl.st_ptr.p; O.gu_ptr = envl.gu_ptr.p; O.qu_ptr = envl.qu_ptr.p; O.appos = E.appos.p;
+        O.l_idx = d_col.p; O.lrow = d_lrow.p; O.sab = d_sab.p; O.sba = d_sba.p; O.pid = d_pid.p; O.diag_pos = d_diag.p;
+        O.st_idx = envl.st_idx.p; O.st_val = envl.st_val.p;
+        O.gain_x = envl.gain_x.p; O.gain_y = envl.gain_y.p; O.asso_x = envl.asso_x.p; O.asso_y = envl.asso_y.p; O.asso_pos = d_apos.p;
+        hipLaunchKernelGGL((k_pat_fill<T>), dim3(grid_rows(K)), dim3(BLOCK), 0, st, K, A, E.P.thr, E.rx.p, E.rxT.p, E.asso.p, O);
+        MMW_HIP(hipGetLastError());
+        // the column indices first: the host-side blockings start on them while the device finishes the rest
+        H.l_indices.resize(nnz);
+        MMW_TRY(copy_d2h(H.l_indices.data(), d_col.p, nnz * sizeof(int32_t), st));
+        const double t_struct = tnow();
+        {   // whether the matrix-core blocking is wanted depends on the block's padded width only
+            BlockLayout lay0;
+            std::string lerr;
+            blk_want_mf = sizeof(T) == 4 && !getenv("MMW_NO_MFMA") && make_layout(Z_ * rr, V16<T>::N, lay0, lerr) == MMW_OK && (double)K * lay0.Dpad * 4.0 < 4.0e9;
+        }
+        const char* blk_env = getenv("MMW_BLOCKING");
+        if (!(blk_env && blk_env[0] == '0')) {
+            if (!getenv("MMW_ENV_RCM")) {  // (MMW_ENV_RCM=1: the pattern-only order of the CSR entry point, for comparisons)
+                HB.rcm_cache = spatial_order(K, E.h_sta, 64);
+                HB.grow = false;
+            }
+            blk_thread = std::thread([this]() { host_blockings(); });
+        }
+        hipLaunchKernelGGL(k_pat_mirror, dim3(grid_elems(nnz)), dim3(BLOCK), 0, st, nnz, d_indptr.p, d_col.p, d_lrow.p, d_mirror.p);
+        hipLaunchKernelGGL(k_pat_rowstats, dim3(grid_elems((size_t)K)), dim3(BLOCK), 0, st, K, envl.st_ptr.p, envl.st_val.p, envl.s_sum.p, envl.sq_sum.p);
+        MMW_HIP(hipGetLastError());
+        H.S_sum.resize(K); H.sq_sum.resize(K); H.h_max.resize(K);
+        MMW_TRY(copy_d2h(H.S_sum.data(), envl.s_sum.p, (size_t)K * sizeof(double), st));
+        MMW_TRY(copy_d2h(H.sq_sum.data(), envl.sq_sum.p, (size_t)K * sizeof(double), st));
+        MMW_TRY(copy_d2h(H.h_max.data(), E.h_max.p, (size_t)K * sizeof(double), st));
+        H.norm_H.assign(K, 0.0);
+        H.cH.assign(K, 0.0);
+        {
+            const std::string err = update_slots(H, Z);
+            if (!err.empty()) {
+                if (blk_thread.joinable()) blk_thread.join();
+                return fail(MMW_ERR_ARG, "mmw_create_from_env: " + err);
+            }
+        }
+        MMW_TRY(d_h.upload_cast(H.h_max, st));
+        MMW_TRY(d_ssum.upload_cast(H.S_sum, st));
+        std::vector<double> invn(K);
+        for (int k = 0; k < K; ++k) invn[k] = 1.0 / H.norm_H[k];
+        MMW_TRY(d_invn.upload_cast(invn, st));
+        MMW_TRY(d_cH.upload_cast(H.cH, st));
+        envl.host_done = false;
+        const double t_1 = tnow();
+        env_src = &E;
+        const int rc = init_common(t_0, t_1, t_struct, &E);
+        env_src = nullptr;
+        return rc;
+    }
+    int env_maxdeg = 1, env_maxq = 1;
+    // the rounding's view of the state, from the generator's own CSR of S_gain (diagonal dropped) and Q
+    int init_extras_env(EnvDevice& E) {
+        MMW_TRY(extras.init_device(st, K, &kt, env_maxdeg, env_maxq));
+        std::vector<int32_t> so_ptr_h((size_t)K + 1);
+        MMW_TRY(copy_d2h(so_ptr_h.data(), envl.so_ptr.p, so_ptr_h.size() * sizeof(int32_t), st));
+        const size_t nso = (size_t)so_ptr_h[K];
+        MMW_TRY(extras.so_indptr.upload(so_ptr_h, st));
+        MMW_TRY(extras.so_indices.alloc(nso)); MMW_TRY(extras.so_data.alloc(nso)); MMW_TRY(extras.so_hmax.alloc(nso));
+        MMW_TRY(extras.q_indptr.alloc((size_t)K + 1)); MMW_TRY(extras.q_indices.alloc((size_t)E.nnzQ)); MMW_TRY(extras.h_max.alloc(K));
+        hipLaunchKernelGGL(k_pat_so_fill, dim3(grid_rows(K)), dim3(BLOCK), 0, st, K, (const int*)E.s_ptr.p, (const int*)E.s_idx.p, (const double*)E.s_val.p,
+                           (const int*)extras.so_indptr.p, (const double*)E.h_max.p, extras.so_indices.p, extras.so_data.p, extras.so_hmax.p);
+        MMW_HIP(hipGetLastError());
+        MMW_HIP(hipMemcpyAsync(extras.q_indptr.p, E.q_ptr.p, ((size_t)K + 1) * sizeof(int), hipMemcpyDeviceToDevice, st));
+        MMW_HIP(hipMemcpyAsync(extras.q_indices.p, E.q_idx.p, (size_t)E.nnzQ * sizeof(int), hipMemcpyDeviceToDevice, st));
+        MMW_HIP(hipMemcpyAsync(extras.h_max.p, E.h_max.p, (size_t)K * sizeof(double), hipMemcpyDeviceToDevice, st));
+        MMW_HIP(hipStreamSynchronize(st));
+        return MMW_OK;
+    }
+
+    // ---- everything after the pattern is on the device: the iterate's buffers, the engine, the blockings, the rounding side
+    int init_common(double t_0, double t_1, double t_struct, EnvDevice* env) {
+        const bool verbose = getenv("MMW_VERBOSE") != nullptr;
+        auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         const size_t nnz = (size_t)H.nnzL(), C = (size_t)H.C();
         MMW_TRY(lval.alloc(nnz)); MMW_TRY(xval.alloc(nnz)); MMW_TRY(xavg.alloc(nnz));
         MMW_TRY(Y.alloc(C)); MMW_TRY(yavg.alloc(C)); MMW_TRY(e_accu.alloc(C)); MMW_TRY(e_this.alloc(C));
@@ -290,7 +461,8 @@ template <typename T> struct Solver final : mmw_solver {
         MMW_TRY(out64.alloc(big));
         MMW_TRY(stage64.alloc((size_t)K * D));
         MMW_HIP(hipStreamSynchronize(st));
-        MMW_TRY(extras.init(this->st, &H, K, &kt));
+        if (env) MMW_TRY(init_extras_env(*env));
+        else MMW_TRY(extras.init(this->st, &H, K, &kt));
         return reset(nit);
     }
 
@@ -331,7 +503,7 @@ template <typename T> struct Solver final : mmw_solver {
         const int Kp = H.K;
         bool rows_ok = true;
         for (int k = 0; k < Kp && rows_ok; ++k) rows_ok = H.l_indptr[k + 1] - H.l_indptr[k] <= BLK_UNION;
-        if (rows_ok) HB.rcm_cache = rcm_order(Kp, H.l_indptr, H.l_indices);
+        if (rows_ok && HB.rcm_cache.size() != (size_t)Kp) HB.rcm_cache = rcm_order(Kp, H.l_indptr, H.l_indices);  // (a handle made from the generator brings a spatial order)
         const int mrows = getenv("MMW_MF_ROWS") ? atoi(getenv("MMW_MF_ROWS")) : 64;
         std::thread mf_thread;
         if (blk_want_mf && rows_ok) mf_thread = std::thread([&]() { build_mfma_blocking(HB, Kp, H.l_indptr, H.l_indices, std::min(64, std::max(1, mrows))); });
@@ -434,10 +606,11 @@ template <typename T> struct Solver final : mmw_solver {
             if (!getenv("MMW_NO_MFMA_SDDMM")) {
                 MMW_TRY(b_tbase.upload(HB.m_tbase, st)); MMW_TRY(b_tptr.upload(HB.m_tptr, st)); MMW_TRY(b_trc.upload(HB.m_trc, st));
                 MMW_TRY(b_e2w.upload(HB.m_e2w, st));
-                {
-                    std::vector<int32_t> xa(H.asso_pos.size());
-                    for (size_t i = 0; i < xa.size(); ++i) xa[i] = HB.m_e2w[(size_t)H.asso_pos[i]];
-                    MMW_TRY(b_xasso.upload(xa, st));
+                {   // slot of every association pair: the slot of its upper entry
+                    const size_t na = (size_t)H.E_asso();
+                    MMW_TRY(b_xasso.alloc(na));
+                    if (na) hipLaunchKernelGGL(k_gather_idx, dim3(grid_elems(na)), dim3(BLOCK), 0, st, na, (const int*)d_apos.p, (const int*)b_e2w.p, b_xasso.p);
+                    MMW_HIP(hipGetLastError());
                 }
                 n_xs = (size_t)HB.m_nedges + (size_t)K;
                 MMW_TRY(xs_val.alloc(n_xs));
@@ -1345,6 +1518,7 @@ template <typename T> struct Solver final : mmw_solver {
         }
         MMW_HIP(hipSetDevice(device));
         MMW_TRY(sync());
+        if (which == MMW_F_ST_DATA) MMW_TRY(ensure_host_lists());
         const size_t nnz = (size_t)H.nnzL(), C = (size_t)H.C();
         switch (which) {
             case MMW_F_Y: return export_T(Y.p, C, out, n);
@@ -1406,6 +1580,7 @@ template <typename T> struct Solver final : mmw_solver {
         return MMW_OK;
     }
     int read_i32(int which, int32_t* out, int64_t n) override {
+        MMW_TRY(ensure_host_lists());
         switch (which) {
             case MMW_I_L_INDPTR: return export_i32(H.l_indptr, out, n);
             case MMW_I_L_INDICES: return export_i32(H.l_indices, out, n);
@@ -1548,6 +1723,29 @@ int mmw_create(mmw_solver** out, int device, int dtype, int32_t K, int32_t Z, in
     }
     return rc;
 }
+int mmw_create_from_env(mmw_solver** out, mmw_env* env, int dtype, int32_t Z, int32_t rank_radio, double eta, int32_t nit) {
+    if (!out || !env) return fail(MMW_ERR_ARG, "mmw_create_from_env: null pointer");
+    *out = nullptr;
+    if (rank_radio < 1) return fail(MMW_ERR_ARG, "rank_radio must be >= 1");
+    if (nit < 1) return fail(MMW_ERR_ARG, "nit must be >= 1");
+    int rc;
+    if (dtype == MMW_F32) {
+        auto s = std::make_unique<Solver<float>>();
+        rc = s->init_env(env->e.device, env->e, Z, rank_radio, eta, nit);
+        if (rc == MMW_OK) *out = s.release();
+    } else if (dtype == MMW_F64) {
+        auto s = std::make_unique<Solver<double>>();
+        rc = s->init_env(env->e.device, env->e, Z, rank_radio, eta, nit);
+        if (rc == MMW_OK) *out = s.release();
+    } else {
+        rc = fail(MMW_ERR_ARG, "dtype must be MMW_F32 or MMW_F64");
+    }
+    return rc;
+}
+int mmw_env_bounds(mmw_env* e, int32_t out[2]) {
+    if (!e || !out) return fail(MMW_ERR_ARG, "null pointer");
+    return e->e.bounds(out);
+}
 int mmw_destroy(mmw_solver* s) {
     delete s;
     return MMW_OK;
@@ -1617,9 +1815,6 @@ int mmw_sym_eig(int device, int32_t b, const double* G, double rel_tol, int32_t 
 }
 
 // ---- problem generator and scorer on the device (include/mmw_hip.h) ----------------------------------------
-struct mmw_env {
-    mmw::EnvDevice e;
-};
 int mmw_env_create(mmw_env** out, int device, int32_t K, int32_t A, const double* sta_xy, const double* ap_xy, double fre_Hz, double txp_offset,
                    double min_s_n_ratio, double min_sinr, double noise_floor_dbm) {
     if (!out || !sta_xy || !ap_xy) return fail(MMW_ERR_ARG, "mmw_env_create: null pointer");

@@ -31,10 +31,14 @@ struct HostPattern {
     std::vector<int32_t> so_indptr, so_indices;
     std::vector<double> so_data;
     std::vector<int32_t> q_indptr, q_indices;
+    // A handle built on the device (pattern_device.h) keeps the lists that only the API's reads need on the device until someone asks:
+    // their sizes are known from the count pass (>= 0 here), and sq_sum stands in for the pass over st_data in update_slots.
+    int64_t n_st = -1, n_gain = -1, n_asso = -1;
+    std::vector<double> sq_sum;  // [K] sum_j S_T'[k][j]^2 (ascending j)
     int64_t nnzL() const { return (int64_t)l_indices.size(); }
-    int64_t nnzST() const { return (int64_t)st_indices.size(); }
-    int64_t E_asso() const { return (int64_t)asso_x.size(); }
-    int64_t E_gain() const { return (int64_t)gain_x.size(); }
+    int64_t nnzST() const { return n_st >= 0 ? n_st : (int64_t)st_indices.size(); }
+    int64_t E_asso() const { return n_asso >= 0 ? n_asso : (int64_t)asso_x.size(); }
+    int64_t E_gain() const { return n_gain >= 0 ? n_gain : (int64_t)gain_x.size(); }
     int64_t C() const { return E_asso() + 2 * (int64_t)K; }
 };
 
@@ -56,7 +60,9 @@ static inline std::string update_slots(HostPattern& P, int32_t Z) {
     P.Z = Z;
     for (int32_t k = 0; k < K; ++k) {
         double q = 0.0;
-        for (int32_t i = P.st_indptr[k]; i < P.st_indptr[k + 1]; ++i) q += P.st_data[i] * P.st_data[i];
+        if (!P.sq_sum.empty()) q = P.sq_sum[k];
+        else
+            for (int32_t i = P.st_indptr[k]; i < P.st_indptr[k + 1]; ++i) q += P.st_data[i] * P.st_data[i];
         const double s = P.S_sum[k];
         const double invK = 1.0 / (double)K;
         const double c = invK * P.h_max[k] - invK / (double)Z * s;

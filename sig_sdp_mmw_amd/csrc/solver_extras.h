@@ -23,8 +23,20 @@ template <typename T> struct Extras {
     DevBuf<T> g_x, g_l, g_y, g_e1, g_e2, g_r, g_vec, g_tm;
     DevBuf<double> g_part, g_scal, g_lz, g_colsum;
 
+    int maxdeg_h = 1, maxq_h = 1;  // longest row of S_gain without its diagonal / of Q (the greedy kernels' LDS budget)
+    // the rounding's state straight from the device generator (mmw_create_from_env): so_* / q_* / h_max are filled by the caller's kernels
+    int init_device(hipStream_t s, int K_, KernelTimers* k, int maxdeg, int maxq) {
+        st = s; H = nullptr; K = K_; kt = k;
+        maxdeg_h = std::max(1, maxdeg); maxq_h = std::max(1, maxq);
+        MMW_TRY(ghdr.alloc((size_t)K));
+        return fac.init(st, K, kt);
+    }
     int init(hipStream_t s, const HostPattern* h, int K_, KernelTimers* k) {
         st = s; H = h; K = K_; kt = k;
+        for (int q = 0; q < K; ++q) {
+            maxdeg_h = std::max(maxdeg_h, H->so_indptr[q + 1] - H->so_indptr[q]);
+            maxq_h = std::max(maxq_h, H->q_indptr[q + 1] - H->q_indptr[q]);
+        }
         MMW_TRY(so_indptr.upload(H->so_indptr, st));
         MMW_TRY(so_indices.upload(H->so_indices, st));
         MMW_TRY(so_data.upload(H->so_data, st));
@@ -200,11 +212,7 @@ template <typename T> struct Extras {
         MMW_HIP(hipGetLastError());
         if (kt) MMW_TRY(kt->begin(KT_GREEDY));
         {
-            int maxdeg = 1, maxq = 1;
-            for (int k = 0; k < K; ++k) {
-                maxdeg = std::max(maxdeg, H->so_indptr[k + 1] - H->so_indptr[k]);
-                maxq = std::max(maxq, H->q_indptr[k + 1] - H->q_indptr[k]);
-            }
+            int maxdeg = maxdeg_h, maxq = maxq_h;
             maxdeg = (maxdeg + 1) / 2 * 2;  // keep the int arrays after the doubles 8-byte aligned
             if (getenv("MMW_GREEDY_SEQ") && (maxdeg > 4 * BLOCK || maxq > 4 * BLOCK || Z > 4 * BLOCK))
                 return fail(MMW_ERR_ARG, "mmw_round: more than 1024 neighbours / slots per user is not supported by the sequential greedy kernel");

@@ -80,13 +80,13 @@ class mmw(STATS_OBJECT, sdp_solver):
         tic = self._get_tic()
         ret = self._run(Z, state)
         tim = self._get_tim(tic)
-        K = state[0].shape[0]
+        K = self._state_K(state)
         self._add_np_log("mmw_all_it", bs_iteration, np.array([Z, K, tim]))
         return ret
 
     def _run(self, Z, state):
         sp_tic = self._get_tic()
-        K = state[0].shape[0]
+        K = self._state_K(state)
         nit = int(self.nit)
         warm = self.warm_start and self._same_state(state) and self._dev[2].iterations_done > 0
         if warm:  # continue from the previous probe's iterate and average fewer iterations

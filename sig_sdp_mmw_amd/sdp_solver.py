@@ -29,12 +29,18 @@ class sdp_solver:
         return (S.shape[0], S.nnz, Q.nnz, float(S.data[:8].sum()) if S.nnz else 0.0, int(S.indices[:8].sum()) if S.nnz else 0,
                 float(np.asarray(h)[:8].sum()))
 
+    @staticmethod
+    def _state_K(state):
+        return state.K if isinstance(state, _lib.DeviceState) else state[0].shape[0]
+
     def _same_state(self, state):
         """Content comparison with the arrays the handle was created from (copies taken then): in-place edits of
         `S.data` between two calls are seen, like the reference which re-reads the state on every run (mmw.py:28)."""
         if self._dev is None:
             return False
         key, held, _ = self._dev
+        if isinstance(state, _lib.DeviceState) or isinstance(held, _lib.DeviceState):
+            return held is state  # a device-resident state is immutable: identity is content
         if key != self._state_key(state):
             return False
         S, Q, h = state
@@ -52,6 +58,11 @@ class sdp_solver:
                 s.set_slots(max(int(Z), 2), max(int(nit), 1), warm=warm)
             return s
         self.close()
+        if isinstance(state, _lib.DeviceState):  # straight from the device generator: no host copy of the state at all
+            s = _lib.Solver.from_env(state.env, max(int(Z), 2), max(int(nit), 1), 0.1 if eta is None else eta, rank_radio=self.rank_radio,
+                                     dtype=self._dtype_code)
+            self._dev = (None, state, s)
+            return s
         s = _lib.Solver(max(int(Z), 2), state, max(int(nit), 1), 0.1 if eta is None else eta, rank_radio=self.rank_radio,
                         dtype=self._dtype_code, device=self._device_index)
         S, Q, h = state
