@@ -36,11 +36,49 @@ inline int make_layout(int D, int vec, BlockLayout& lay, std::string& err) {
     return MMW_OK;
 }
 
+// The generic SpMM's small-K form (k_spmm_slice): bytes of a staged row slice (0: not applicable) and the row ranges of its grid --
+// the partial slabs a Lanczos launch really fills
+template <typename T> inline int slice_bytes(int K, const BlockLayout& lay) {
+    static const bool off = getenv("MMW_NO_SLICE_SPMM") != nullptr;
+    const int row_bytes = lay.Dpad * (int)sizeof(T);
+    if (off || K < 256) return 0;
+    if ((size_t)K * 64 <= (size_t)SLICE_LDS_MAX && row_bytes % 64 == 0) return 64;
+    if ((size_t)K * 32 <= (size_t)SLICE_LDS_MAX && row_bytes % 32 == 0) return 32;
+    return 0;
+}
+template <typename T> inline int slice_ranges(int K, const BlockLayout& lay, int sb) {
+    const int nslices = lay.Dpad * (int)sizeof(T) / sb;
+    // a slice takes most of a CU's LDS: one workgroup per CU, ONE round of them (a second round stages everything again)
+    return std::max(1, std::min((K + 15) / 16, device_cus() / std::max(1, nslices)));
+}
+// slabs of partial sums a Lanczos launch of the generic path fills (the rest of the caller's `nblk` slabs it clears)
+template <typename T> inline int generic_slabs(int K, const BlockLayout& lay, int nblk) {
+    const int sb = slice_bytes<T>(K, lay);
+    return sb ? std::min(nblk, slice_ranges<T>(K, lay, sb)) : nblk;
+}
 // one launch of the CSR SpMM (any fused epilogue) for a block with layout `lay`
 template <typename T, int MODE>
 inline int spmm_launch(hipStream_t st, int K, const BlockLayout& lay, int nblk, const int* indptr, const int* col, const T* val,
                        const T* in, T* out, T* F, const T* X2, double c1, double c2, double c3, double* partial,
-                       const ExpmPlan* plan = nullptr, int step = 0, double* partial_o2 = nullptr) {
+                       const ExpmPlan* plan = nullptr, int step = 0, double* partial_o2 = nullptr, int nslabs_fold = -1) {
+    if (const int sb = slice_bytes<T>(K, lay)) {  // small K without locality: the block's column slices staged in LDS (k_spmm_slice)
+        const int nslices = lay.Dpad * (int)sizeof(T) / sb;
+        int nranges = slice_ranges<T>(K, lay, sb);
+        if (MODE == SPMM_LANCZOS) nranges = std::min(nranges, nblk);
+        const int fold = nslabs_fold > 0 ? nslabs_fold : nblk;  // slabs the caller folds: the kernel clears the ones past its own
+        const size_t lds = (size_t)K * sb;
+        if (sb == 64) {
+            MMW_TRY(set_max_lds(reinterpret_cast<const void*>(&k_spmm_slice<T, MODE, 64>), SLICE_LDS_MAX));
+            hipLaunchKernelGGL((k_spmm_slice<T, MODE, 64>), dim3(nslices, nranges), dim3(SLICE_THREADS), lds, st, K, lay.Dpad, indptr, col, val, in, out, F, X2, c1, c2, c3,
+                               partial, plan, step, partial_o2, fold);
+        } else {
+            MMW_TRY(set_max_lds(reinterpret_cast<const void*>(&k_spmm_slice<T, MODE, 32>), SLICE_LDS_MAX));
+            hipLaunchKernelGGL((k_spmm_slice<T, MODE, 32>), dim3(nslices, nranges), dim3(SLICE_THREADS), lds, st, K, lay.Dpad, indptr, col, val, in, out, F, X2, c1, c2, c3,
+                               partial, plan, step, partial_o2, fold);
+        }
+        MMW_HIP(hipGetLastError());
+        return MMW_OK;
+    }
     const size_t sh = MODE == SPMM_LANCZOS ? (size_t)WAVES_PER_BLOCK * lay.Dpad * sizeof(double) : 0;
     switch (lay.NCH) {
         case 1: hipLaunchKernelGGL((k_spmm<T, 1, MODE>), dim3(nblk), dim3(BLOCK), sh, st, K, lay, indptr, col, val, in, out, F, X2, c1, c2, c3, partial, plan, step, partial_o2); break;
@@ -253,7 +291,7 @@ template <typename T> struct ExpmEngine {
         MMW_TRY(partial_sq.alloc((size_t)MAX_PART * lay.Dpad));
         MMW_TRY(partial_du.alloc((size_t)MAX_PART * lay.Dpad));
         MMW_TRY(partial_o2.alloc(slabs * lay.Dpad));
-        npart = nblk;
+        npart = generic_slabs<T>(K, lay, nblk);
         MMW_TRY(colsum.alloc(lay.Dpad));
         MMW_TRY(scal.alloc((size_t)4 * (MAX_ORDER + 2) * lay.Dpad));
         MMW_TRY(row_part.alloc((size_t)3 * ROW_GRID_MAX));
@@ -361,7 +399,7 @@ template <typename T> struct ExpmEngine {
                                               apost() ? partial_o2.p : nullptr)));
         else
             MMW_TRY((spmm_launch<T, MODE>(st, K, lay, nblk, indptr, col, val, in, out, F, nullptr, ascale, shift, inv_k, partial.p, plan, step,
-                                          apost() ? partial_o2.p : nullptr)));
+                                          apost() ? partial_o2.p : nullptr, npart)));
         return kend();
     }
     int enable_blocking(const BlkDev& b, const T* values_blocked) {

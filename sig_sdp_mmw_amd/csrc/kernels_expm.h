@@ -227,6 +227,165 @@ __global__ __launch_bounds__(BLOCK) void k_spmm(int K, BlockLayout lay, const in
     }
 }
 
+// ---- SpMM with the Krylov block staged in LDS, for small K without locality (BASELINE configs[1] / [3]: N = 2 000, 5 % dense) -----
+// The generic kernel gathers a dense row of U from L2 for every nonzero (400 k nonzeros x 512 B at N = 2 000, D = 64, fp64: 205 MB per
+// product for a 1 MB block).  When a column slice of the WHOLE block fits the CU's LDS -- K rows x SB bytes, SB = 64 (8 fp64 / 16 fp32
+// columns) up to K = 2 400, SB = 32 up to 4 800 -- a workgroup stages its slice once and serves every nonzero of its row range from
+// LDS; the matrix (12 / 8 B per nonzero) is streamed once per slice.  Grid = (slices, row ranges); a wave takes a row (see the loop).
+// The Lanczos epilogue reads u[row] from the staged slice.  Same epilogues and the same partial-slab
+// layout as k_spmm: range r writes slab r, and range 0 clears the slabs [nranges, nslabs) that the caller folds as well.
+constexpr int SLICE_LDS_MAX = 153600;   // bytes of LDS a slice may take (160 KB per CU, a little left for the reductions)
+constexpr int SLICE_THREADS = 1024;
+template <typename T, int MODE, int SB>
+__global__ __launch_bounds__(SLICE_THREADS) void k_spmm_slice(int K, int Dpad, const int* __restrict__ indptr, const int* __restrict__ col, const T* __restrict__ val,
+                                                              const T* __restrict__ U, T* __restrict__ Out, T* __restrict__ F, const T* __restrict__ X2,
+                                                              double ascale, double shift, double inv_k, double* __restrict__ partial,
+                                                              const ExpmPlan* __restrict__ plan, int step, double* __restrict__ partial_o2, int nslabs) {
+    constexpr int CS = SB / (int)sizeof(T);  // columns per slice
+    constexpr int NG = WAVE / CS;            // nonzeros per wave step
+    constexpr int NWV = SLICE_THREADS / WAVE;
+    bool shifted = false;
+    if (plan) {
+        if (MODE == SPMM_LANCZOS) {
+            if (step > plan_steps(plan, step - 1)) return;
+            shifted = plan->apost != 0 && partial_o2 != nullptr;
+            if (shifted) shift = plan->mu;
+        } else if (step > plan->m) return;
+        if (MODE == SPMM_TAYLOR) shift = plan->mu / plan->nsub;
+    }
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* us = reinterpret_cast<T*>(smem_raw);  // [K][CS]
+    __shared__ double shd[2][NWV][CS];
+    const int c0 = (int)blockIdx.x * CS, range = (int)blockIdx.y, nranges = (int)gridDim.y;
+    {   // stage the slice: 16-byte pieces, a row's SB bytes contiguous in both places
+        constexpr int Q = SB / 16;
+        const char* src = reinterpret_cast<const char*>(U + c0);
+        const size_t pitch = (size_t)Dpad * sizeof(T);
+        for (int i0 = threadIdx.x; i0 < K * Q; i0 += 8 * SLICE_THREADS) {  // eight loads in flight per thread
+            float4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * SLICE_THREADS;
+                const int row = i / Q, q = i - row * Q;
+                t[u] = i < K * Q ? *reinterpret_cast<const float4*>(src + (size_t)row * pitch + q * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * SLICE_THREADS;
+                if (i < K * Q) *reinterpret_cast<float4*>(smem_raw + (size_t)i * 16) = t[u];
+            }
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int per = (K + nranges - 1) / nranges;
+    const int r0 = range * per, r1 = min(K, r0 + per);
+    // A lane takes ONE nonzero at a time -- the row's entries are read 64 at a time, fully coalesced, four such reads in flight -- and
+    // multiplies it into all CS columns of the slice (SB bytes of LDS).  The 64 x CS partial sums of a row then meet in a
+    // reduce-scatter: each exchange step halves the columns a lane still carries, log2(CS) steps, then log2(64 / CS) plain ones.
+    int colsel = 0;  // the column this lane ends up holding
+#pragma unroll
+    for (int half = CS / 2, bit = 32; half >= 1; half >>= 1, bit >>= 1) colsel += (lane & bit) ? half : 0;
+    const bool owner = (lane & (NG - 1)) == 0;
+    double dot = 0.0, dot2 = 0.0;
+    // two rows per wave in flight (their entry reads are independent: one memory round trip for both)
+    for (int rowA = r0 + wv; rowA < r1; rowA += 2 * NWV) {
+        const int rowB = rowA + NWV;
+        const bool hasB = rowB < r1;
+        int beg[2], end[2];
+        beg[0] = indptr[rowA]; end[0] = indptr[rowA + 1];
+        beg[1] = hasB ? indptr[rowB] : 0; end[1] = hasB ? indptr[rowB + 1] : 0;
+        T acc[2][CS];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int k = 0; k < CS; ++k) acc[r][k] = T(0);
+        const int len = max(end[0] - beg[0], end[1] - beg[1]);
+        for (int o0 = lane; o0 - lane < len; o0 += 4 * WAVE) {
+            int cc[2][4];
+            T vv[2][4];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = beg[r] + o0 + u * WAVE;
+                    const bool ok = e < end[r];
+                    cc[r][u] = ok ? col[e] : 0;
+                    vv[r][u] = ok ? val[e] : T(0);
+                }
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4* src = reinterpret_cast<const float4*>(smem_raw + (size_t)cc[r][u] * SB);
+#pragma unroll
+                    for (int q = 0; q < SB / 16; ++q) {
+                        const float4 x4 = src[q];
+                        constexpr int PER = 16 / (int)sizeof(T);
+                        T x[PER];
+                        __builtin_memcpy(x, &x4, 16);
+#pragma unroll
+                        for (int k = 0; k < PER; ++k) acc[r][q * PER + k] += vv[r][u] * x[k];
+                    }
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            int bit = 32;
+#pragma unroll
+            for (int half = CS / 2; half >= 1; half >>= 1, bit >>= 1) {
+                const bool up = (lane & bit) != 0;
+#pragma unroll
+                for (int k = 0; k < half; ++k) {
+                    const T mine = up ? acc[r][k + half] : acc[r][k];
+                    const T other = up ? acc[r][k] : acc[r][k + half];
+                    acc[r][k] = mine + lane_xor(other, bit);
+                }
+            }
+#pragma unroll
+            for (int b2 = NG / 2; b2 >= 1; b2 >>= 1) acc[r][0] += lane_xor(acc[r][0], b2);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int row = r ? rowB : rowA;
+            if (owner && (r == 0 || hasB)) {
+                const int c = colsel;
+                const size_t off = (size_t)row * Dpad + c0 + c;
+                T o;
+                if (MODE == SPMM_PLAIN) o = (T)(ascale * (double)acc[r][0]);
+                else if (MODE == SPMM_LANCZOS) {
+                    const T u = us[(size_t)row * CS + c];
+                    o = (T)(ascale * (double)acc[r][0] - shift * (double)u);
+                    dot += (double)u * (double)o;
+                    dot2 += (double)o * (double)o;
+                } else if (MODE == SPMM_AXPBY) o = (T)(ascale * (double)acc[r][0] + shift * (double)F[off] + inv_k * (double)X2[off]);
+                else {
+                    const T u = us[(size_t)row * CS + c];
+                    o = (T)((ascale * (double)acc[r][0] - shift * (double)u) * inv_k);
+                    F[off] = F[off] + o;
+                }
+                Out[off] = o;
+            }
+        }
+    }
+    if (MODE == SPMM_LANCZOS) {
+        if (owner) { shd[0][wv][colsel] = dot; shd[1][wv][colsel] = dot2; }
+        __syncthreads();
+        if ((int)threadIdx.x < CS) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int w = 0; w < NWV; ++w) { s1 += shd[0][w][threadIdx.x]; s2 += shd[1][w][threadIdx.x]; }
+            partial[(size_t)range * Dpad + c0 + threadIdx.x] = s1;
+            if (shifted) partial_o2[(size_t)range * Dpad + c0 + threadIdx.x] = s2;
+        }
+        if (range == 0)  // the slabs no range owns
+            for (int i = threadIdx.x; i < (nslabs - nranges) * CS; i += SLICE_THREADS) {
+                const int sl = nranges + i / CS, cc2 = i % CS;
+                partial[(size_t)sl * Dpad + c0 + cc2] = 0.0;
+                if (shifted) partial_o2[(size_t)sl * Dpad + c0 + cc2] = 0.0;
+            }
+    }
+}
+
 // ---- LDS-staged SpMM over locality blocks (blocking.h) ------------------------------------------
 // One workgroup (8 waves) per (row block, 256-byte column tile):
 //   phase 1  gathers the block's union of dense rows into LDS (each row segment one coalesced 256-B read,
