@@ -209,6 +209,9 @@ def main():
     ap.add_argument("--coloring-cold", action="store_true", help="(kept for compatibility: the cold, reference-semantics search is always reported as `coloring`)")
     ap.add_argument("--no-coloring-warm", action="store_true", help="skip the additional warm-started search (`coloring_warm_start`)")
     ap.add_argument("--no-fp32-operands", action="store_true", help="skip the second handle with strictly-fp32 operands (`value_fp32_operands`)")
+    ap.add_argument("--state", default="host", choices=["device", "host"],
+                    help="journal workloads: 'device' = the instance is generated on the GPU and handed to the solver there "
+                         "(mmw_env_create -> mmw_create_from_env); 'host' (default, as in rounds 1-2) = the NumPy generator's CSR through mmw_create; the colouring block reports both")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --single-device rehearses N>1 on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="every rank uses GPU 0 (rehearsal only)")
     args = ap.parse_args()
@@ -261,8 +264,16 @@ def main():
     nit = args.warmup + args.steps
     method = _lib.EXPM_LANCZOS if args.expm == "lanczos" else _lib.EXPM_TAYLOR
     solvers = []
-    for st, Z in zip(states, Zs):
-        s = _lib.Solver(Z, st, nit, args.eta, dtype=dtype, device=local_rank)
+    state_mode = "host CSR (mmw_create)"
+    for (st, geo), Z in zip(made, Zs):
+        if args.state == "device" and geo is not None:  # the journal generator on the device, the state handed over there (f2)
+            from sig_sdp_mmw_amd.graphs import min_sinr_dec, _NOISE_FLOOR_DBM
+            env_i = _lib.DeviceEnv(geo["sta_locs"], geo["ap_locs"], min_sinr=min_sinr_dec(), noise_floor_dbm=_NOISE_FLOOR_DBM, device=local_rank)
+            s = _lib.Solver.from_env(env_i, Z, nit, args.eta, dtype=dtype)
+            env_i.close()  # the handle keeps nothing of the generator
+            state_mode = "device-resident (mmw_env_create -> mmw_create_from_env)"
+        else:
+            s = _lib.Solver(Z, st, nit, args.eta, dtype=dtype, device=local_rank)
         s.set_expm(method, 12, 1e-6 if dtype_name == "f32" else 1e-9)
         solvers.append(s)
     solver, state, Z = solvers[0], states[0], Zs[0]
@@ -455,7 +466,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
         "config": {"workload": args.workload, "description": desc, "K": K, "Z": Z, "D": D, "nnzL": nnzL, "C": C,
-                   "eta": args.eta, "expm": args.expm, "krylov_order": m_used, "first_order_steps": first_iters, "first_order_one_half_matrix_steps": first16_iters, "rng": "device-philox4x32",
+                   "eta": args.eta, "expm": args.expm, "krylov_order": m_used, "first_order_steps": first_iters, "first_order_one_half_matrix_steps": first16_iters, "rng": "device-philox4x32", "state": state_mode,
                    "operand_precision": operand_precision,
                    "instances": n_inst, "instances_per_gpu": M,
                    "parallelism": "instance-sharded x%d" % world + (", %d resident per GPU" % M if M > 1 else "")},

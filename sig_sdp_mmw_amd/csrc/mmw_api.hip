@@ -808,6 +808,20 @@ template <typename T> struct Solver final : mmw_solver {
                 life_max = std::max(life_max, (double)q[4]);
                 epi += (double)q[7];
             }
+            {   // the slowest twentieth of the waves, and lifetime against the block's k-steps
+                std::vector<std::pair<unsigned long long, size_t>> byl;
+                for (size_t w = 0; w < h.size() / 8; ++w) if (h[w * 8 + 4]) byl.push_back({h[w * 8 + 4], w});
+                std::sort(byl.rbegin(), byl.rend());
+                const size_t top = std::max<size_t>(1, byl.size() / 20);
+                double ts[8] = {0};
+                for (size_t i = 0; i < top && i < byl.size(); ++i) for (int k = 0; k < 8; ++k) ts[k] += (double)h[byl[i].second * 8 + k];
+                if (!byl.empty())
+                    fprintf(stderr, "[mf stamps] slowest %zu waves: chunks %.1f, prologue %.0f, wait+barrier %.0f, issue %.0f, products %.0f, epilogue %.0f, lifetime %.0f\n", top, ts[5] / top,
+                            ts[0] / top, ts[1] / top, ts[2] / top, ts[3] / top, ts[7] / top, ts[4] / top);
+                double lo = 0, hi = 0; int nlo = 0, nhi = 0;
+                for (auto& pr : byl) { const unsigned long long* q = &h[pr.second * 8]; if (q[5] <= 6) { lo += (double)q[4]; ++nlo; } else if (q[5] >= 9) { hi += (double)q[4]; ++nhi; } }
+                fprintf(stderr, "[mf stamps] lifetime of waves with <= 6 chunks: %.0f (%d waves); with >= 9 chunks: %.0f (%d waves)\n", nlo ? lo / nlo : 0.0, nlo, nhi ? hi / nhi : 0.0, nhi);
+            }
             if (n)
                 fprintf(stderr, "[mf stamps] %d waves, %.1f k-steps each; shader clocks per wave: prologue %.0f, wait+barrier %.0f (%.0f/step), issue %.0f (%.0f/step), "
                                 "products %.0f (%.0f/step), epilogue %.0f, lifetime %.0f (max %.0f)\n", n, steps / n, sum[0] / n, sum[1] / n, sum[1] / steps,

@@ -16,7 +16,7 @@ STUB = os.path.join(ROOT, "tests", "helpers", "rank_stub.py")
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])  # 8: the driver's scaling run (one rank per GPU of a node), rehearsed on the CPU
 def test_launcher_starts_ranks_and_relays_rank0(world):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     rc, out = bench.spawn_ranks(world, [sys.executable, STUB], env=env, timeout=240)

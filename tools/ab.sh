@@ -6,7 +6,7 @@ if [ "$1" = "-w" ]; then W=$2; shift 2; fi
 cd $GRAFT_REPO_ROOT
 for v in "$@"; do
   echo "== [$v] $W"
-  env $v python bench.py --workload $W --cpu-iters 0 --no-coloring --no-fp32-operands --repeats 5 2>/dev/null | python -c "
+  env $v python bench.py $BENCH_ARGS --workload $W --cpu-iters 0 --no-coloring --no-fp32-operands --repeats 5 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print(d['value'], d['value_min'], d['value_max'], 'first', d['config']['first_order_steps'], d['config']['first_order_one_half_matrix_steps'], d['device_us_per_step'], 'spmm', d['roofline']['avg_launch_us'], d['roofline']['frac'])"

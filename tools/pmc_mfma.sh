@@ -6,9 +6,9 @@ TAG=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_mfma
 rm -rf $OUT; mkdir -p $OUT
-for c in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA SQ_INSTS_VALU"; do
+for c in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA SQ_INSTS_VALU" "SQ_INSTS_VALU_MFMA_MOPS_F16"; do
   n=$(echo $c | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$n -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --cpu-iters 0 > $OUT/$n.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$n -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --cpu-iters 0 --no-fp32-operands --no-coloring-warm > $OUT/$n.log 2>&1
 done
 python3 - <<PY
 import csv, glob, json, collections

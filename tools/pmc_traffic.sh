@@ -8,11 +8,11 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic
 rm -rf $OUT; mkdir -p $OUT
 # shipped path first (optimistic chunks: the exponential as one first-order product, k_spmm_mfma<4, ...>: every launch of it does work)
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/S_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 150 --warmup 10 --cpu-iters 0 --no-coloring > $OUT/S_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/S_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 150 --warmup 10 --cpu-iters 0 --no-coloring --no-fp32-operands > $OUT/S_$c.log 2>&1
 done
 export MMW_SYNC_PLAN=1   # exact launches only: no early-exited stages in the per-kernel means (Lanczos epilogue, k_spmm_mfma<1, ...>)
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --cpu-iters 0 --no-coloring > $OUT/$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --cpu-iters 0 --no-coloring --no-fp32-operands > $OUT/$c.log 2>&1
 done
 python3 - <<PY
 import csv, glob, json, collections
