@@ -1177,7 +1177,8 @@ template <typename T> struct Solver final : mmw_solver {
         const int gr = grid_rows(K);
         const int C = (int)H.C();
         const int gc = grid_elems((size_t)C);
-        const int gl = (int)std::min<size_t>(((size_t)H.nnzL() + BLOCK - 1) / BLOCK, (size_t)LOSS_GRID_MAX);  // LOSS: one thread per stored entry
+        static const int loss_grid_cap = getenv("MMW_LOSS_GRID") ? atoi(getenv("MMW_LOSS_GRID")) : LOSS_GRID_MAX;
+        const int gl = (int)std::min<size_t>(((size_t)H.nnzL() + BLOCK - 1) / BLOCK, (size_t)std::max(1, std::min(loss_grid_cap, LOSS_GRID_MAX)));  // LOSS: one thread per stored entry, grid-stride
         const int Dpad = eng.lay.Dpad;
         int m_launch = optimistic ? m_guess : 0;
         // from the plan the last settled chunk ended on; not in the first chunk after a warm restart: with another slot count the matrix grows
