@@ -18,12 +18,21 @@ gathered with one RCCL all_gather that closes the timed region.
 --instances-per-gpu M (BASELINE configs[3]: 64 N=2000 graphs, 8 per GPU: `--workload er-5pct-2k
 --instances-per-gpu 8`): M resident handles per rank, their iterations enqueued round-robin on M HIP streams.
 
+`value` is the MEDIAN of --repeats (7) timed regions -- each: back to the initial point, W untimed warm-up steps, exactly K
+steps between two barriers (+ device synchronisation), closed by the gather of the objective records -- with `value_min` /
+`value_max`, the tail of the median region (`region_tail_ms`: read-back, gather, barrier) and the rate without it.
+`config.operand_precision` says what the fp32 headline multiplies in (16-bit operands on the matrix cores, fp32 accumulation,
+certified against the tolerance); `value_fp32_operands` is the same loop on strictly-fp32 operands (N = 1).
+
 The JSON line also carries
   roofline     : the CSR SpMM inside exp(L/2)R -- algorithmic bytes per launch
                  divided by its mean launch duration, measured with HIP events on the solver's stream
                  in a second pass over the same steps;
   coloring     : wall-clock of the binary search on the slot count down to a feasible colouring of the same instance
-                 (rank 0, N = 1, one instance per GPU), with the per-probe phase times;
+                 (rank 0, N = 1, one instance per GPU), with the per-probe phase times -- the REFERENCE's search: every probe
+                 restarts from Y = 1/C, X = I and runs nit iterations (mmw.py:62-68), state through the host CSR;
+  coloring_device_state : the same search with the state handed over on the device (mmw_env_create -> mmw_create_from_env);
+  coloring_warm_start   : the opt-in warm-started variant (NOT the reference's search), labelled as such;
   cpu_baseline : the CPU oracle (oracle/mmw_oracle.py, a NumPy/SciPy port of the reference loop)
                  timed on this host on a bounded number of iterations of the same instance (rank 0, N=1).
 """
