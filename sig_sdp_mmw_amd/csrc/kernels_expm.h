@@ -1148,6 +1148,7 @@ __device__ __forceinline__ double texp_core(int Dpad, int c, int m, double inv_n
         for (int k = 1; k <= 30; ++k) {
             double tn[NMAX];
             double big = 0.0;
+            const double isq_k = isq / (double)k;  // ONE division per term (a double-precision division per element was most of this launch's time)
 #pragma unroll
             for (int j = 0; j < NMAX; ++j) {
                 double v = 0.0;
@@ -1158,7 +1159,7 @@ __device__ __forceinline__ double texp_core(int Dpad, int c, int m, double inv_n
                 } else if (j < n) {
                     v = t[j > 0 ? j - 1 : 0];  // the augmented rows e_m^T and e_{m+1}^T
                 }
-                tn[j] = v * isq / k;
+                tn[j] = v * isq_k;
                 big = fabs(tn[j]) > big ? fabs(tn[j]) : big;
             }
 #pragma unroll
