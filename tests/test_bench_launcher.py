@@ -64,3 +64,22 @@ def test_bench_instances_per_gpu_config3_shape():
     assert d["n_gpus"] == 1 and d["config"]["instances"] == 4 and d["config"]["instances_per_gpu"] == 4
     assert len(d["objectives"]["max_violation_per_instance"]) == 4
     assert abs(d["instances_per_s"] * 8 - d["value"]) < 1e-2 * d["value"] + 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_line_carries_the_round3_fields_and_the_device_state_path():
+    """One short run with the instance generated on the GPU and handed over there (--state device): the line still carries every
+    contract field, the spread of the timed regions, the operand disclosure and the three colouring records."""
+    d = _run_bench(["--steps", "8", "--warmup", "4", "--cpu-iters", "2", "--repeats", "3", "--state", "device", "--no-fp32-operands"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "value_min", "value_max", "timed_regions", "region_tail_ms"):
+        assert k in d, k
+    assert d["timed_regions"] == 3 and d["value_min"] <= d["value"] <= d["value_max"]
+    assert "device-resident" in d["config"]["state"] and "operand_precision" in d["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    assert d["coloring"]["warm_start"] is False and d["coloring"]["rem"] == 0
+    assert d["coloring_device_state"]["rem"] == 0 and "device-resident" in d["coloring_device_state"]["state"]
+    assert d["coloring_warm_start"]["warm_start"] is True
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
