@@ -1175,6 +1175,11 @@ template <typename T> struct Solver final : mmw_solver {
         const PatternDev<T> P = pat();
         const T* const xcur = x_tiles ? xs_val.p : xval.p;  // the X the DUAL phase reads (the layout does not change inside a call)
         const int gr = grid_rows(K);
+        // the DUAL pass's grid: its workgroups stride over the row pairs, and the slabs it leaves (maxima, softmax sums, |L| row sums) are
+        // folded by one workgroup afterwards.  One resident round of workgroups (five per CU at the pass's 86 registers) instead of one per
+        // eight rows: half the slabs to fold and no second round's tail -- DUAL 21.0 -> 20.0 us per step at the benchmark (640: 22.3; 1920: 20.2)
+        static const int dual_cap = getenv("MMW_DUAL_GRID") ? atoi(getenv("MMW_DUAL_GRID")) : 0;
+        const int gd = std::min(gr, dual_cap > 0 ? dual_cap : 5 * device_cus());
         const int C = (int)H.C();
         const int gc = grid_elems((size_t)C);
         static const int loss_grid_cap = getenv("MMW_LOSS_GRID") ? atoi(getenv("MMW_LOSS_GRID")) : LOSS_GRID_MAX;
@@ -1216,7 +1221,7 @@ template <typename T> struct Solver final : mmw_solver {
             PlanArgs pa;
             if (lagged_it) {
                 pa.plan = eng.plan_d.p; pa.part = eng.row_part.p; pa.viol = eng.viol_d.p; pa.tol = eng.tol; pa.K = K; pa.method = eng.method;
-                pa.max_order = eng.max_order; pa.np = gr; pa.m_launch = m_launch; pa.apost = eng.apost() ? 1 : 0; pa.iter_seen = age() - 1;
+                pa.max_order = eng.max_order; pa.np = gd; pa.m_launch = m_launch; pa.apost = eng.apost() ? 1 : 0; pa.iter_seen = age() - 1;
             }
             // Inside a chunk (not its first iteration) the softmax rides in k_dual_h, shifted by the previous iteration's maximum
             // instead of this one's: one small workgroup then folds the sums, and the LOSS pass normalises where it reads
@@ -1225,18 +1230,18 @@ template <typename T> struct Solver final : mmw_solver {
             if (fused_dual) {
                 ++n_fused_iters;
                 if (yun.n < (size_t)C) MMW_TRY(yun.alloc((size_t)C));
-                hipLaunchKernelGGL((k_dual_h<T>), dim3(gr), dim3(BLOCK), 0, st, P, rsum.p, e_this.p, e_accu.p, eta, max_part.p,
+                hipLaunchKernelGGL((k_dual_h<T>), dim3(gd), dim3(BLOCK), 0, st, P, rsum.p, e_this.p, e_accu.p, eta, max_part.p,
                                    (const T*)(lagged_it ? lval.p : nullptr), 0.5, eng.row_part.p, (const double*)(scal.p + 4), yun.p, wH.p, sum_part.p,
                                    rs_it, xcur);
-                hipLaunchKernelGGL(k_dual_scal, dim3(1 + fv.nwg), dim3(DSCAL_THREADS), 0, st, sum_part.p, max_part.p, gr, scal.p,
+                hipLaunchKernelGGL(k_dual_scal, dim3(1 + fv.nwg), dim3(DSCAL_THREADS), 0, st, sum_part.p, max_part.p, gd, scal.p,
                                    dual_gap, eng.viol_d.p, fv);
             } else {
-                hipLaunchKernelGGL((k_dual_h<T>), dim3(gr + fv.nwg), dim3(BLOCK), 0, st, P, rsum.p, e_this.p, e_accu.p, eta, max_part.p,
+                hipLaunchKernelGGL((k_dual_h<T>), dim3(gd + fv.nwg), dim3(BLOCK), 0, st, P, rsum.p, e_this.p, e_accu.p, eta, max_part.p,
                                    (const T*)(lagged_it ? lval.p : nullptr), 0.5, eng.row_part.p, (const double*)nullptr, (T*)nullptr, (T*)nullptr,
                                    (double*)nullptr, rs_it, xcur, fv);
-                hipLaunchKernelGGL((k_softmax_a<T>), dim3(gc), dim3(BLOCK), 0, st, P, e_accu.p, Y.p, max_part.p, gr, sum_part.p);
+                hipLaunchKernelGGL((k_softmax_a<T>), dim3(gc), dim3(BLOCK), 0, st, P, e_accu.p, Y.p, max_part.p, gd, sum_part.p);
                 hipLaunchKernelGGL((k_softmax_b<T>), dim3(gc + (lagged_it ? 1 : 0)), dim3(BLOCK), 0, st, C, Y.p, yavg.p, acc, sum_part.p, gc, scal.p,
-                                   K + (int)H.E_asso(), d_invn.p, wH.p, pa, max_part.p, gr);
+                                   K + (int)H.E_asso(), d_invn.p, wH.p, pa, max_part.p, gd);
             }
             MMW_TRY(kt.end());
             MMW_TRY(record(1));
