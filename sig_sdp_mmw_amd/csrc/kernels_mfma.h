@@ -599,12 +599,12 @@ struct FirstVerify {
     double cA = 0.0;           // relative rounding of the matrix image the product read (see above)
     double du_scale = 1.0;     // tests only (MMW_FV_DU_SCALE): inflates the measured rounding to force a miss
 };
-// workgroup `wg` (256 or 1024 threads) takes the columns [FV_COLS wg, FV_COLS (wg + 1)).  Lane (q = lane & 7, slice = lane >> 3) of wave w sums
+// workgroup `wg` (4 to 16 wavefronts) takes the columns [FV_COLS wg, FV_COLS (wg + 1)).  Lane (q = lane & 7, slice = lane >> 3) of wave w sums
 // column q over the slab rows 8 w + slice, + 8 waves, ...: a load covers 8 rows x 64 bytes, and a wave's 24 sums meet in three strided
 // reductions (lanes of equal q) instead of 24 whole-wave ones.  Fixed order throughout.
 __device__ inline void first_verify(const FirstVerify& V, int wg) {
     __shared__ double shv[3 * FV_COLS][16];
-    const int BLOCK_V = (int)blockDim.x, NWV = BLOCK_V >> 6;  // 256 or 1024 threads
+    const int BLOCK_V = (int)blockDim.x, NWV = BLOCK_V >> 6;  // 4 ... 16 wavefronts
     const int c0 = wg * FV_COLS;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, q8 = lane & 7, sl = lane >> 3;
     double a_o2 = 0.0, a_u2 = 0.0, a_du = 0.0;
@@ -654,8 +654,24 @@ __global__ __launch_bounds__(4 * MT * 64)
 void k_sddmm_mfma(MfmaDev M, SdMfmaDev S, int K, int Dpad, const char* __restrict__ Ypl, const float* __restrict__ d,
                   const double* __restrict__ tr_part, int ntr, float* __restrict__ xs_val, float* __restrict__ xs_avg, int accumulate,
                   long long* __restrict__ rsfx = nullptr /* [K], zero at launch */, const long long* __restrict__ dfx = nullptr,
-                  unsigned long long* __restrict__ stamps = nullptr /* diagnostic runs: 8 shader-clock sums per wave */) {
+                  unsigned long long* __restrict__ stamps = nullptr /* diagnostic runs: 8 shader-clock sums per wave */,
+                  FirstVerify V = FirstVerify{}) {
     // dfx: the row norms as 2^-40 fixed-point totals (SPMM_FIRST) instead of `d`
+    // V.plan: the launch carries 8 more columns of workgroups (one per XCD and union-tile group) that take no tiles: they certify the
+    // first-order exponential this X comes from (first_verify; its slabs are complete once the product has ended) -- short independent
+    // work in the slots the one round of tile workgroups leaves free, instead of riding on the DUAL phase's critical path.
+    {
+        const int nbx = ((M.nb + 7) >> 3) << 3;
+        if ((int)blockIdx.x >= nbx) {
+            if (!V.plan) return;
+            const int nfv = 8 * (int)gridDim.y;
+            for (int cg = ((int)blockIdx.x - nbx) + 8 * (int)blockIdx.y; cg < V.nwg; cg += nfv) {
+                first_verify(V, cg);
+                __syncthreads();  // the next column group reuses first_verify's LDS
+            }
+            return;
+        }
+    }
     unsigned long long tk0 = 0, tk1 = 0, acc_wait = 0, acc_issue = 0, acc_comp = 0, t_pro = 0, t_red = 0, t_store = 0;
     if (stamps) tk0 = __builtin_amdgcn_s_memtime();
     const int by = (int)blockIdx.y;  // union-tile group of this workgroup

@@ -134,6 +134,7 @@ template <typename T> struct Solver final : mmw_solver {
     long long n_first_iters = 0;
     bool rs_last = false;    // the last iteration enqueued left rsfx for the X the next one starts from
     const bool rs_enabled = getenv("MMW_NO_SDDMM_ROWSUMS") == nullptr;
+    const bool fv_in_sddmm = !(getenv("MMW_FV_IN_SDDMM") && atoi(getenv("MMW_FV_IN_SDDMM")) == 0);  // where the first-order certificate's workgroups run
     long long n_rs_iters = 0, n_fused_iters = 0;  // MMW_F_DUAL_INFO
     bool sddmm_mfma = false;
     size_t afrag_n = 0;
@@ -1343,7 +1344,17 @@ template <typename T> struct Solver final : mmw_solver {
                     const long long* dfx = first_it ? rsfx.p + K : nullptr;
                     const double* trp = first_it ? tr1_part.p : tr_part.p;
                     const int ntr = first_it ? ntr1 : gr;
-                    const dim3 grid((HB.nbm() + 7) / 8 * 8, (HB.m_ntile_max + SDM_GT - 1) / SDM_GT);
+                    // the certificate of this iteration's first-order exponential rides in this launch (8 more columns of workgroups)
+                    FirstVerify fv_now;
+                    if (first_it) {
+                        fv_now.plan = eng.plan_d.p; fv_now.viol = eng.viol_d.p; fv_now.o2 = eng.partial_o2.p; fv_now.n_o2 = eng.mf.nb;
+                        fv_now.u2 = eng.partial_sq.p; fv_now.du2 = fv_measure ? eng.partial_du.p : nullptr; fv_now.rows = K; fv_now.n_u2 = eng.npart_start; fv_now.Dpad = Dpad;
+                        fv_now.nwg = Dpad / FV_COLS;
+                        fv_now.cA = first_a16_guess ? F16_UNIT : F16_CA_TWO;
+                        fv_now.du_scale = fv_du_scale;
+                    }
+                    const bool fv_rides = first_it && fv_in_sddmm;
+                    const dim3 grid((HB.nbm() + 7) / 8 * 8 + (fv_rides ? 8 : 0), (HB.m_ntile_max + SDM_GT - 1) / SDM_GT);
                     SM.tmask = b_tmask.p;
                     long long* rs_out = rs_zeroed ? rsfx.p : nullptr;  // this iteration's LOSS pass zeroed the totals
                     // MMW_SD_STAMPS=1 (developer aid): per-wave phase clocks of the last iteration's launch, printed to stderr
@@ -1359,7 +1370,8 @@ template <typename T> struct Solver final : mmw_solver {
     do {                                                                                                                                     \
         MMW_TRY(set_max_lds(reinterpret_cast<const void*>(&k_sddmm_mfma<MT, NB>), sdm_lds_bytes<MT, NB>()));                                 \
         hipLaunchKernelGGL((k_sddmm_mfma<MT, NB>), grid, dim3(256 * MT), (sdm_lds_bytes<MT, NB>()), st, eng.mf, SM, K, Dpad,                 \
-                           reinterpret_cast<const char*>(xh_planes.p), drow.p, trp, ntr, xs_val.p, xs_avg.p, acc, rs_out, dfx, sdm_stamps.p); \
+                           reinterpret_cast<const char*>(xh_planes.p), drow.p, trp, ntr, xs_val.p, xs_avg.p, acc, rs_out, dfx, sdm_stamps.p,  \
+                           fv_rides ? fv_now : FirstVerify{});                                                                               \
     } while (0)
                     if (HB.mfma_mt == 2) { if (sd_nb == 3) MMW_SDM_LAUNCH(2, 3); else MMW_SDM_LAUNCH(2, 2); }
                     else { if (sd_nb == 3) MMW_SDM_LAUNCH(1, 3); else MMW_SDM_LAUNCH(1, 2); }
@@ -1401,13 +1413,8 @@ template <typename T> struct Solver final : mmw_solver {
                                     grid.x, grid.y, nw, sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[3] / nw, sum[5] / nw, sum[7] / nw, sum[4] / nw, life_max, (double)(tmax - tmin));
                     }
                     sd_done = true;
-                    if (first_it) {  // certified by spare workgroups of the next iteration's k_dual_h, or by a launch of its own after the chunk's last
-                        fv_pending.plan = eng.plan_d.p; fv_pending.viol = eng.viol_d.p; fv_pending.o2 = eng.partial_o2.p; fv_pending.n_o2 = eng.mf.nb;
-                        fv_pending.u2 = eng.partial_sq.p; fv_pending.du2 = fv_measure ? eng.partial_du.p : nullptr; fv_pending.rows = K; fv_pending.n_u2 = eng.npart_start; fv_pending.Dpad = Dpad;
-                        fv_pending.nwg = Dpad / FV_COLS;
-                        fv_pending.cA = first_a16_guess ? F16_UNIT : F16_CA_TWO;
-                        fv_pending.du_scale = fv_du_scale;
-                    }
+                    // (MMW_FV_IN_SDDMM=0: certified by spare workgroups of the next iteration's DUAL phase, or by a launch of its own after the chunk's last)
+                    if (first_it && !fv_rides) fv_pending = fv_now;
                     rs_ok = rs_out != nullptr;
                 }
             }
