@@ -107,7 +107,10 @@ int mmw_sizes(mmw_solver* s, int64_t out[10]);
 
 /* Krylov scheme for exp(L/2)R, max order per substep (<= 16) and target relative accuracy. */
 int mmw_set_expm(mmw_solver* s, int method, int max_order, double tol);
-/* 1: record HIP events around every phase (fills MMW_F_PHASE_US); 0: none, iterations run back to back. */
+/* 1: record HIP events around every phase of every iteration (fills MMW_F_PHASE_US, the reference's per-iteration timers
+ * mmw.py:142,170,197,200); 0: none, iterations run back to back; S > 1: events only in iteration 0 and in one iteration of every S
+ * (four event records per iteration are four barrier packets in the chain of dependent launches): MMW_F_PHASE_US still has one row per
+ * iteration, the rows of a group of S iterations repeat the group's sample -- the harness takes means (sim_mmw_time.py:48-52). */
 int mmw_set_timing(mmw_solver* s, int enabled);
 
 /* 1: bracket every kernel class with HIP events on the solver's stream (fills MMW_F_KERNEL_US), plans read back every iteration and

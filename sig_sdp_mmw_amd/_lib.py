@@ -179,7 +179,8 @@ class Solver:
         check(lib().mmw_set_expm(self._h, int(method), int(max_order), float(tol)))
 
     def set_timing(self, on):
-        check(lib().mmw_set_timing(self._h, 1 if on else 0))
+        """False / 0: off; True / 1: phase events in every iteration; S > 1: in one iteration of every S (rows repeated in between)."""
+        check(lib().mmw_set_timing(self._h, int(on)))
         self._timing = bool(on)
 
     def set_profile(self, on):

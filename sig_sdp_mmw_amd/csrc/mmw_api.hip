@@ -156,6 +156,10 @@ template <typename T> struct Solver final : mmw_solver {
     std::vector<hipEvent_t> events;  // 4 per timed iteration
     std::vector<hipEvent_t> event_pool;  // events of earlier runs, kept for reuse
     std::vector<double> phase_us;
+    struct PhaseSample { int it; double us[4]; };
+    std::vector<PhaseSample> phase_samples;  // the iterations that carried events (set_timing)
+    std::vector<int> ev_iter;                // iteration of every group of four pending events
+    int timing_stride = 1;
     uint64_t last_seed = 0;
     bool last_was_rng = false;
 
@@ -652,8 +656,13 @@ template <typename T> struct Solver final : mmw_solver {
     }
     int set_timing(int enabled) override {
         timing = enabled != 0;
+        timing_stride = enabled > 1 ? enabled : 1;
         return MMW_OK;
     }
+    // Phase timers of every iteration cost the loop four event records per iteration (each one a barrier packet between two launches of
+    // the dependent chain).  With a stride S > 1 only iteration 0 and the iterations i = S/2 (mod S) carry events; every other row of
+    // MMW_F_PHASE_US repeats the sample of its group of S iterations (the harness takes means over the rows, sim_mmw_time.py:48-52).
+    bool timed_iteration() const { return timing && (timing_stride <= 1 || iter == 0 || iter % timing_stride == timing_stride / 2); }
     // diagnostic: per-workgroup phase stamps written by a blocked kernel (16 slots per workgroup, slot 9 = end,
     // 10 = HW_ID, 11 = XCC_ID): mean time per phase and how many workgroups were resident per CU
     int dump_stamps(const unsigned long long* dev) {
@@ -902,6 +911,7 @@ template <typename T> struct Solver final : mmw_solver {
         else MMW_HIP(hipMemcpyAsync(xavg.p, xval.p, nnz * sizeof(T), hipMemcpyDeviceToDevice, st));
         MMW_HIP(hipMemcpyAsync(yavg.p, Y.p, C * sizeof(T), hipMemcpyDeviceToDevice, st));
         phase_us.clear();
+        phase_samples.clear();
         return MMW_OK;
     }
     int reset(int32_t nit_) override {
@@ -937,11 +947,13 @@ template <typename T> struct Solver final : mmw_solver {
         hipLaunchKernelGGL((k_fill<T>), dim3(grid_elems(C)), dim3(BLOCK), 0, st, C, yavg.p, y0);
         MMW_HIP(hipGetLastError());
         phase_us.clear();
+        phase_samples.clear();
         return MMW_OK;
     }
 
     int record(int slot) {
-        if (!timing) return MMW_OK;
+        if (!timed_iteration()) return MMW_OK;
+        if (slot == 0) ev_iter.push_back(iter);
         hipEvent_t e;
         if (!event_pool.empty()) {  // events are kept across runs: creating four per iteration cost the class path ~20 us per iteration
             e = event_pool.back();
@@ -962,10 +974,26 @@ template <typename T> struct Solver final : mmw_solver {
             MMW_HIP(hipEventElapsedTime(&b, events[i + 1], events[i + 2]));
             MMW_HIP(hipEventElapsedTime(&c, events[i + 2], events[i + 3]));
             MMW_HIP(hipEventElapsedTime(&t, events[i], events[i + 3]));
-            phase_us.push_back(a * 1e3); phase_us.push_back(b * 1e3); phase_us.push_back(c * 1e3); phase_us.push_back(t * 1e3);
+            phase_samples.push_back({ev_iter[i / 4], {a * 1e3, b * 1e3, c * 1e3, t * 1e3}});
         }
         for (auto e : events) event_pool.push_back(e);
         events.clear();
+        ev_iter.clear();
+        // one row per iteration done: its own sample, else the sample of its group of `timing_stride` iterations, else the nearest one
+        phase_us.clear();
+        if (phase_samples.empty()) return MMW_OK;
+        std::sort(phase_samples.begin(), phase_samples.end(), [](const PhaseSample& x, const PhaseSample& y) { return x.it < y.it; });
+        const int S = std::max(1, timing_stride);
+        for (int i = 0; i < iter; ++i) {
+            const int want = (i == 0 || S <= 1) ? i : (i / S) * S + S / 2;
+            const PhaseSample* best = nullptr;
+            for (const PhaseSample& q : phase_samples) {
+                if (q.it == want) { best = &q; break; }
+                if (q.it == 0 && i != 0 && phase_samples.size() > 1) continue;  // the first iteration of a run is not like the others
+                if (!best || std::abs(q.it - i) < std::abs(best->it - i)) best = &q;
+            }
+            for (int k = 0; k < 4; ++k) phase_us.push_back(best->us[k]);
+        }
         return MMW_OK;
     }
 
@@ -1040,6 +1068,7 @@ template <typename T> struct Solver final : mmw_solver {
             MMW_HIP(hipStreamSynchronize(st));
             for (size_t i = pend_events0; i < events.size(); ++i) event_pool.push_back(events[i]);
             events.resize(std::min(events.size(), pend_events0));
+            ev_iter.resize(events.size() / 4);
         }
         return iterate_impl(pend_n, nullptr, pend_seed, false);
     }

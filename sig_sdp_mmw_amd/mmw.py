@@ -94,7 +94,10 @@ class mmw(STATS_OBJECT, sdp_solver):
         solver = self._device_solver(Z, state, nit=nit, eta=self.eta, need_loop=True, warm=warm)
         self._add_np_log("mmw_iters", 0, np.array([Z, K, nit, 1.0 if warm else 0.0]))
         solver.set_expm(_lib.EXPM_LANCZOS if self.expm == "lanczos" else _lib.EXPM_TAYLOR, self.expm_max_order, self.expm_tol)
-        solver.set_timing(True)
+        # the reference's per-iteration phase timers (mmw.py:142,170,197,200).  The reference-exact path (host draws, one call per chunk of
+        # sketches) times every iteration; the fast path one iteration of every MMW_PHASE_TIMING (default 8; 1: all, 0: none -- rows of zeros)
+        stride = 1 if self.rng == "host" else int(os.environ.get("MMW_PHASE_TIMING", "8"))
+        solver.set_timing(stride)
         D = solver.D
         self._add_np_log("mmw_state_process", 0, np.array([Z, K, self._get_tim(sp_tic)]))
 
@@ -118,7 +121,7 @@ class mmw(STATS_OBJECT, sdp_solver):
             done += n
             self.N_STEP = done
         solver.sync()
-        us = solver.read(_lib.F_PHASE_US).reshape(nit, 4)
+        us = solver.read(_lib.F_PHASE_US).reshape(nit, 4) if stride > 0 else np.zeros((nit, 4))
         steps = np.arange(nit)
         zk = np.tile(np.array([Z, K], dtype=np.float64), (nit, 1))
         for key, col in (("mmw_dual", 0), ("mmw_loss", 1), ("mmw_expm", 2), ("mmw_per_it", 3)):

@@ -391,3 +391,30 @@ def test_first_order_product_with_the_matrix_in_one_fp16_half(monkeypatch):
     for f, x in zip(FIELDS, got):
         assert relerr(x, b.read(f)) < 2e-5, f
     b.close()
+
+
+def test_sampled_phase_timers_keep_one_row_per_iteration():
+    """mmw_set_timing(S > 1): events in iteration 0 and in one iteration of every S; MMW_F_PHASE_US still has a row per iteration
+    (the harness takes means over them, sim_mmw_time.py:48-52) and the iterate is the one of an untimed run."""
+    state = journal_graph(16, 0.02, seed=4)
+    Z, nit = 24, 40
+    ref = _lib.Solver(Z, state, nit, 0.04, dtype=_lib.F32)
+    ref.iterate(nit, None, seed=5)
+    ref.sync()
+    want = ref.read(_lib.F_XVAL)
+    ref.close()
+    rows = {}
+    for stride in (1, 8):
+        s = _lib.Solver(Z, state, nit, 0.04, dtype=_lib.F32)
+        s.set_timing(stride)
+        s.iterate(25, None, seed=5)
+        s.iterate(nit - 25, None, seed=5)
+        s.sync()
+        us = s.read(_lib.F_PHASE_US).reshape(nit, 4)
+        assert np.all(us > 0) and np.all(np.isfinite(us))
+        assert np.allclose(us[:, :3].sum(axis=1), us[:, 3], rtol=0.05, atol=2.0)  # the three phases make the iteration
+        assert relerr(s.read(_lib.F_XVAL), want) < 1e-6
+        rows[stride] = us
+        s.close()
+    assert len(np.unique(rows[8][8:16, 3])) == 1 and len(np.unique(rows[1][8:16, 3])) > 1  # a group repeats its sample
+    assert 0.5 < rows[8][:, 3].mean() / rows[1][:, 3].mean() < 1.5
