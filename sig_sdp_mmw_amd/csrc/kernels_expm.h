@@ -43,6 +43,10 @@ struct ExpmPlan {      // written by k_plan, read by every expm kernel
     unsigned conv[MAX_ORDER + 2];  // conv[j]: float bits of the largest per-column estimate after j steps (valid once step j's scalars ran)
     unsigned first_est;  // float bits of the largest per-column error bound of the first-order form y = u + (A - mu I) u (first_order_bound)
 };
+// why an optimistic chunk has to be replayed (bits of the violation word the host reads when it settles the chunk)
+enum : int { VIOL_ORDER = 1 /* the launched Lanczos steps did not meet the tolerance */, VIOL_LAGGED = 2 /* an extrapolated plan did not cover its matrix */,
+             VIOL_PLAN = 4 /* substeps / overflow */, VIOL_SOFTMAX = 8 /* the fused softmax's shift ran away */, VIOL_OPERANDS = 16 /* 16-bit operand gate */,
+             VIOL_FIRST = 32 /* the first-order form's certificate missed */ };
 constexpr double F16_UNIT = 4.8828125e-4;                 // 2^-11, the unit roundoff of fp16 (11 significant bits)
 constexpr double F16_PLANE_EXPECT = 0.45 * F16_UNIT;      // ||u - fp16(u)|| / ||u|| of a row-normalised Gaussian block: 0.434 * 2^-11 measured
 constexpr double F16_CA_TWO = 4.8e-7;                      // the matrix as fp16 hi + lo: 2 * 2^-22 relative per entry
@@ -1341,7 +1345,7 @@ __global__ __launch_bounds__(BLOCK) void k_lz_combine(int K, int Dpad, int m, co
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             plan->m_eff = m;
             // the host launched fewer steps than the a-priori order and the estimate did not accept them either: replay
-            if (plan->apost && plan->m_apriori > plan->m && m == plan->m && plan->conv[m] > __float_as_uint((float)plan->tol) && viol) *viol = 1;
+            if (plan->apost && plan->m_apriori > plan->m && m == plan->m && plan->conv[m] > __float_as_uint((float)plan->tol) && viol) atomicOr(viol, VIOL_ORDER);
         }
     }
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -1534,7 +1538,7 @@ __device__ __forceinline__ void plan_body(int K, int method, int max_order, doub
             const double need = pp - old.mu > pm + old.mu ? pp - old.mu : pm + old.mu;
             const double absn_seen = pp > pm ? pp : pm;
             // ... and the row-sum bound every gate and certificate of that product used (mfma_ok, f16_ok, f16a_ok, first_verify)
-            if (need > old.rho || absn_seen > old.absn) *viol = 1;
+            if (need > old.rho || absn_seen > old.absn) atomicOr(viol, VIOL_LAGGED);
         }
         // history and growth per iteration
         p.h_iter = old.h_iter; p.h_pp = old.h_pp; p.h_pm = old.h_pm; p.h_mu = old.h_mu;
@@ -1588,7 +1592,7 @@ __device__ __forceinline__ void plan_body(int K, int method, int max_order, doub
         if (m_launch > 0 && (nsub > 1 || m > m_launch || p.overflow)) {
             // more than the host launched: with the estimate on, the combination decides whether the launched steps were
             // enough after all; without it the batch is replayed
-            if (!(p.apost && nsub == 1 && !p.overflow)) *viol = 1;
+            if (!(p.apost && nsub == 1 && !p.overflow)) atomicOr(viol, VIOL_PLAN);
             p.m = m < m_launch ? m : m_launch;  // keep the launched kernels in range
             p.nsub = 1;
         }
@@ -1619,7 +1623,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_verify(int K, const doubl
         const double mu = tr / K;
         if (p.lagged && iter_seen == p.h_iter + 1) {
             const double need = pp - p.mu > pm + p.mu ? pp - p.mu : pm + p.mu;
-            if (need > p.rho || (pp > pm ? pp : pm) > p.absn) *viol = 1;  // see plan_body
+            if (need > p.rho || (pp > pm ? pp : pm) > p.absn) atomicOr(viol, VIOL_LAGGED);  // see plan_body
         }
         if (iter_seen > p.h_iter) {
             const double dt = (double)(iter_seen - p.h_iter);

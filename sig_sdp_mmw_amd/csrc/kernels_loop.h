@@ -353,7 +353,7 @@ __global__ __launch_bounds__(DSCAL_THREADS) void k_dual_scal(const double* __res
         scal[2] = s3 / total;
         scal[3] = total;
         scal[4] = m;
-        if (!(m - m0 <= overflow_gap) || !(total > 0.0) || !(total < 1e300)) *viol = 1;
+        if (!(m - m0 <= overflow_gap) || !(total > 0.0) || !(total < 1e300)) atomicOr(viol, VIOL_SOFTMAX);
     }
 }
 

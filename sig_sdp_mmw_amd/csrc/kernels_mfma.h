@@ -179,7 +179,7 @@ void k_spmm_mfma(MfmaDev M, int Dpad, size_t plane_bytes, const char* __restrict
             shift_d = plan->mu;
         } else if (step > plan->m) return;
         // launched without a plan readback on a matrix whose norm has outgrown the two-half split: the chunk is replayed on the fp32 kernel
-        if (!(A16 ? plan->f16a_ok : (F16 ? plan->f16_ok : plan->mfma_ok)) && viol && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *viol = 1;
+        if (!(A16 ? plan->f16a_ok : (F16 ? plan->f16_ok : plan->mfma_ok)) && viol && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicOr(viol, VIOL_OPERANDS);
     }
     const float ascale = (float)ascale_d, shift = (float)shift_d;
     static_assert(NW % MS == 0 && MT % MS == 0, "row tiles and waves split evenly");
@@ -643,7 +643,7 @@ __device__ inline void first_verify(const FirstVerify& V, int wg) {
             atomicMax(&V.plan->conv[1], up(best));  // maxima: the order of arrival does not matter (the plan zeroed both)
             atomicMax(&V.plan->first_est, up(best_t));
             if (wg == 0) V.plan->m_eff = 1;
-            if (!(best <= V.plan->tol) || !V.plan->apost || V.plan->nsub != 1 || V.plan->overflow) *V.viol = 1;
+            if (!(best <= V.plan->tol) || !V.plan->apost || V.plan->nsub != 1 || V.plan->overflow) atomicOr(V.viol, VIOL_FIRST);
         }
     }
 }

@@ -150,6 +150,8 @@ template <typename T> struct Solver final : mmw_solver {
     size_t pend_events0 = 0;  // phase-timer events recorded before the pending chunk
     uint64_t pend_seed = 0;
     int replays = 0;
+    bool exact_plans_only = false;  // a cautious second attempt at a discarded chunk is running (settle)
+    const bool cautious_replay = !(getenv("MMW_CAUTIOUS_REPLAY") && atoi(getenv("MMW_CAUTIOUS_REPLAY")) == 0);
     ExpmEngine<T> eng;
     Extras<T> extras;
     KernelTimers kt;
@@ -1048,6 +1050,34 @@ template <typename T> struct Solver final : mmw_solver {
         return MMW_OK;
     }
     // a batch enqueued without plan readbacks is verified here; a violated batch is replayed synchronously
+    // A chunk that ends with a violation is discarded and run again from its snapshot.  The second attempt is still a chunk without
+    // readbacks, but a cautious one: Lanczos steps (no first-order form) at the a-priori order plus one, an exact plan in front of every
+    // exponential (no extrapolated ones), the softmax in its two passes for the first iteration.  Only if that one is refused as well --
+    // or the matrix has outgrown the 16-bit split of the matrix-core product, which only the per-iteration readback steps around --
+    // do the iterations run synchronously (~2.5x the time per iteration).  Hard probes of a bisection (slot counts at the edge of
+    // feasibility: the matrix grows faster than any history predicts) took 3 replays per 150 iterations, 29 ms instead of 13.
+    int restore_pending() {
+        chain_ok = false;
+        MMW_TRY(eng.clear_violation());
+        MMW_TRY(copy_state(false));
+        iter = pend_iter0;
+        if (timing) {  // drop the timers of the discarded chunk (earlier chunks keep theirs)
+            MMW_HIP(hipStreamSynchronize(st));
+            for (size_t i = pend_events0; i < events.size(); ++i) event_pool.push_back(events[i]);
+            events.resize(std::min(events.size(), pend_events0));
+            ev_iter.resize(events.size() / 4);
+        }
+        return MMW_OK;
+    }
+    void say_replay(int viol, const char* how) const {
+        if (!getenv("MMW_VERBOSE")) return;
+        const ExpmPlan& p = eng.last;
+        union { unsigned u; float f; } c1, fe;
+        c1.u = p.conv[std::max(0, std::min(p.m_eff, MAX_ORDER))]; fe.u = p.first_est;
+        fprintf(stderr, "[replay] iterations %d..%d (Z %d) %s: reason bits %d (1 order, 2 lagged plan, 4 plan, 8 softmax, 16 operands, 32 first-order certificate); launched m %d, first-order %d, one-half %d; "
+                        "plan m %d m_eff %d apriori %d rho %.3g absn %.3g est %.2e first_est %.2e tol %.1e\n",
+                pend_iter0, pend_iter0 + pend_n - 1, (int)H.Z, how, viol, m_guess, (int)first_guess, (int)first_a16_guess, p.m, p.m_eff, p.m_apriori, p.rho, p.absn, (double)c1.f, (double)fe.f, p.tol);
+    }
     int settle() {
         if (!pending) return MMW_OK;
         pending = false;
@@ -1060,15 +1090,28 @@ template <typename T> struct Solver final : mmw_solver {
             return MMW_OK;
         }
         ++replays;
-        chain_ok = false;
-        MMW_TRY(eng.clear_violation());
-        MMW_TRY(copy_state(false));
-        iter = pend_iter0;
-        if (timing) {  // drop the timers of the discarded chunk (earlier chunks keep theirs)
-            MMW_HIP(hipStreamSynchronize(st));
-            for (size_t i = pend_events0; i < events.size(); ++i) event_pool.push_back(events[i]);
-            events.resize(std::min(events.size(), pend_events0));
-            ev_iter.resize(events.size() / 4);
+        const bool operands_only = (viol & VIOL_OPERANDS) && !first_guess;  // the bf16 split's gate: the fp32 kernel has to take over
+        say_replay(viol, "discarded");
+        MMW_TRY(restore_pending());
+        if (cautious_replay && !operands_only && eng.method == MMW_EXPM_LANCZOS && pend_n > 1) {
+            first_guess = false;
+            first_a16_guess = false;
+            m_guess = std::min(eng.max_order, std::max(std::max(eng.last.m_apriori, eng.last.m_eff), m_guess) + 1);
+            exact_plans_only = true;
+            const int rc = iterate_impl(pend_n, nullptr, pend_seed, true);
+            exact_plans_only = false;
+            MMW_TRY(rc);
+            viol = 0;
+            MMW_TRY(eng.fetch_plan(&viol));
+            if (!viol) {
+                plan_seen = true;
+                note_plan();
+                m_guess = next_launch_order();
+                return MMW_OK;
+            }
+            ++replays;
+            say_replay(viol, "cautious attempt discarded");
+            MMW_TRY(restore_pending());
         }
         return iterate_impl(pend_n, nullptr, pend_seed, false);
     }
@@ -1093,7 +1136,9 @@ template <typename T> struct Solver final : mmw_solver {
             MMW_TRY(settle());
             // ... or as many as the last settled plan's estimate leaves room for (room_iterations)
             int cap = lagged_ok() ? std::max(8, std::min(32, age())) : std::max(4, std::min(32, age() / 2));
-            if (chain_ok && age() >= 4) cap = std::max(cap, std::min(32, room_iterations()));
+            // (the room is an extrapolation: before two plans of this run have shown how fast the matrix grows, a chunk does not reach
+            // further than the run is old -- at slot counts near infeasibility the norm grew 16x over iterations 4..35, not the 9x of a linear law)
+            if (chain_ok && age() >= 4) cap = std::max(cap, std::min(age_prev >= 0 ? 32 : std::max(8, age()), room_iterations()));
             if (warm_fresh) cap = 8;
             int chunk = std::min(left, cap);
             if (left - chunk == 1) ++chunk;  // no trailing chunk of one iteration: it would run synchronously and break the chain of chunks
@@ -1218,7 +1263,7 @@ template <typename T> struct Solver final : mmw_solver {
         int m_launch = optimistic ? m_guess : 0;
         // from the plan the last settled chunk ended on; not in the first chunk after a warm restart: with another slot count the matrix grows
         // at another rate than the history the extrapolation rests on (its bound was missed and the chunk replayed, measured)
-        const bool lag_chunk = optimistic && lagged_ok() && !warm_fresh;
+        const bool lag_chunk = optimistic && lagged_ok() && !warm_fresh && !exact_plans_only;
         const bool chain = optimistic && chain_ok;          // this chunk continues the previous one (see chain_ok)
         chain_ok = false;
         // the plan is chained only while a single step is accepted with a factor 8 to spare: near a change of order an exact plan at
