@@ -171,7 +171,9 @@ int mmw_gap(mmw_solver* s, double out[3]);
 /*
  * mmw_factor: the epilogue mmw.py:202-216.  Xbar = (sum of X)/nit on the pattern, top-`rank`
  * (by |eigenvalue|) invariant subspace by block Krylov iteration on the device,
- * X_half[K,rank] = V sqrt(|lambda|), columns in ascending |lambda| like svds.  out: K*rank float64.
+ * X_half[K,rank] = V sqrt(|lambda|), columns in ascending |lambda| like svds.  out: K*rank float64, or NULL: the factor stays on
+ * the device (mmw_round takes it from there with gX == NULL; mmw_read_f64(MMW_F_FACTOR) copies it out when asked) -- the caller
+ * binary_search_relaxation.py:50-53 only hands it from run_with_state to rounding.
  */
 int mmw_factor(mmw_solver* s, int32_t rank, double* out, uint64_t seed);
 
@@ -199,6 +201,7 @@ int mmw_sym_eig(int device, int32_t b, const double* G, double rel_tol, int32_t 
  * entry: inprod = randv gX^T on the fp64 matrix cores, per-user slot preference order, the greedy
  * feasibility assignment in descending ||gX_k|| order.  z_out[nbatch,K] gets the slot or -1 for a user
  * left unassigned (the caller draws those, sdp_solver.py:104-105); rem_out[nbatch] the count.
+ * gX == NULL: the K x Dp factor mmw_factor computed last on this handle, read where it lies on the device.
  */
 int mmw_round(mmw_solver* s, int32_t Zr, int32_t Dp, const double* gX, int32_t nbatch, const double* randv,
               int32_t* z_out, int32_t* rem_out);

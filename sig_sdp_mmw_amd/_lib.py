@@ -5,6 +5,7 @@ every entry point raises `MMWError` with the library's message on a non-zero sta
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -160,8 +161,11 @@ class Solver:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
-            lib().mmw_destroy(self._h)
-            self._h = C.c_void_p()
+            try:
+                self._keep_resident_factor()
+            finally:
+                lib().mmw_destroy(self._h)
+                self._h = C.c_void_p()
 
     def __del__(self):
         try:
@@ -290,24 +294,83 @@ class Solver:
         check(lib().mmw_gap(self._h, _pd(out)))
         return out
 
-    def factor(self, rank, seed=0):
+    def factor(self, rank, seed=0, resident=False):
+        """X_half (K, rank) float64.  resident=True: a `DeviceFactor` -- the factor stays on the device, `round` takes it from there,
+        and it becomes a NumPy array (one copy out) the moment anything else looks at it."""
+        self._keep_resident_factor()
+        if resident:
+            check(lib().mmw_factor(self._h, int(rank), None, C.c_uint64(int(seed))))
+            self._factor_serial = getattr(self, "_factor_serial", 0) + 1
+            df = DeviceFactor(self, int(rank), self._factor_serial)
+            self._resident = weakref.ref(df)
+            return df
         out = np.empty((self.K, int(rank)), dtype=np.float64)
         check(lib().mmw_factor(self._h, int(rank), _pd(out), C.c_uint64(int(seed))))
+        self._factor_serial = getattr(self, "_factor_serial", 0) + 1
         return out
+
+    def _keep_resident_factor(self):
+        """A resident factor somebody still holds is copied out before the handle overwrites it (next factor) or goes away (close)."""
+        ref = getattr(self, "_resident", None)
+        df = ref() if ref is not None else None
+        if df is not None and df._host is None and getattr(self, "_h", None) is not None and self._h.value:
+            np.asarray(df)
+        self._resident = None
 
     def round(self, Z, gX, randv):
         """randv: (nbatch, Z, D') row-normalised; returns (z[nbatch,K] int32 with -1 = unassigned, rem[nbatch])."""
-        gX = _f64(gX)
+        on_device = isinstance(gX, DeviceFactor) and gX.on_device_of(self)
+        if not on_device:
+            gX = _f64(gX)
         randv = _f64(randv)
         if randv.ndim == 2:
             randv = randv[None]
         nb, Zr, Dp = randv.shape
-        if Zr != Z or gX.shape != (self.K, Dp):
+        if Zr != Z or tuple(gX.shape) != (self.K, Dp):
             raise MMWError("round: gX must be (K, D') and randv (nbatch, Z, D')")
         z = np.empty((nb, self.K), dtype=np.int32)
         rem = np.empty(nb, dtype=np.int32)
-        check(lib().mmw_round(self._h, int(Z), int(Dp), _pd(gX), int(nb), _pd(randv), _pi(z), _pi(rem)))
+        check(lib().mmw_round(self._h, int(Z), int(Dp), None if on_device else _pd(gX), int(nb), _pd(randv), _pi(z), _pi(rem)))
         return z, rem
+
+
+class DeviceFactor(np.lib.mixins.NDArrayOperatorsMixin):
+    """The X_half of `Solver.factor(resident=True)`: (K, rank) float64 that lives on the device.  The reference hands the factor from
+    `run_with_state` straight to `rounding` (binary_search_relaxation.py:50-53): `Solver.round` recognises this object and reads the factor
+    where it lies.  For everything else it is an array: `np.asarray`, arithmetic, indexing and attribute access copy it out (once)."""
+
+    def __init__(self, solver, rank, serial):
+        self._solver, self._serial, self._host = solver, serial, None
+        self.shape, self.ndim, self.dtype = (solver.K, rank), 2, np.dtype(np.float64)
+
+    def on_device_of(self, solver):
+        """True while `solver` is the handle that made this factor and has not made another one since."""
+        return self._solver is solver and getattr(solver, "_factor_serial", 0) == self._serial and bool(solver._h.value)
+
+    def __array__(self, dtype=None, copy=None):
+        if self._host is None:
+            if not self.on_device_of(self._solver):
+                raise MMWError("this factor was not copied to the host before its handle computed another one (or was closed)")
+            self._host = self._solver.read(F_FACTOR, self.shape[0] * self.shape[1]).reshape(self.shape)
+        return self._host if dtype is None else self._host.astype(dtype, copy=False)
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        return getattr(ufunc, method)(*[np.asarray(x) if isinstance(x, DeviceFactor) else x for x in inputs], **kwargs)
+
+    def __array_function__(self, func, types, args, kwargs):
+        conv = lambda x: np.asarray(x) if isinstance(x, DeviceFactor) else x
+        return func(*[conv(a) for a in args], **{k: conv(v) for k, v in kwargs.items()})
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, idx):
+        return np.asarray(self)[idx]
+
+    def __getattr__(self, name):  # (only reached for what the object itself lacks: T, sum, copy, ...)
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(np.asarray(self), name)
 
 
 class DeviceEnv:

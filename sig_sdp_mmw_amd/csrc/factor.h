@@ -238,6 +238,7 @@ template <typename T> struct Factorizer {
     PinnedBuf last_host;         // [K*rank] float64: the last factor, page-locked (read back by MMW_F_FACTOR too)
     size_t last_n = 0;
     int last_rank = 0;
+    bool last_on_host = false;   // last_host holds the factor that sits in out64
 
     int outer_done = 0;
     double last_resid = 0.0;
@@ -366,7 +367,16 @@ template <typename T> struct Factorizer {
         return MMW_OK;
     }
 
-    // factor of A = ascale * (values `val` on the pattern).  out: K*rank float64 (host)
+    // the page-locked host copy of the factor in out64, made when somebody asks for it
+    int fetch_last(size_t n) {
+        if (last_on_host) return MMW_OK;
+        MMW_TRY(last_host.ensure(n * sizeof(double)));
+        MMW_HIP(hipMemcpyAsync(last_host.p, out64.p, n * sizeof(double), hipMemcpyDeviceToHost, st));
+        MMW_HIP(hipStreamSynchronize(st));
+        last_on_host = true;
+        return MMW_OK;
+    }
+    // factor of A = ascale * (values `val` on the pattern).  out: K*rank float64 (host), or nullptr
     int run(const int* indptr, const int* col, const T* val, double ascale, int rank, uint64_t seed, double* out) {
         if (rank < 1 || rank >= K + 1) return fail(MMW_ERR_ARG, "mmw_factor: rank must be in [1, K]");
         auto vnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -570,9 +580,9 @@ template <typename T> struct Factorizer {
         hipLaunchKernelGGL((k_export_factor<T>), dim3(grid_elems((size_t)K * rank)), dim3(BLOCK), 0, st, K, rank, ld, V.p, dw.perm.p, dw.diag.p, out64.p);
         MMW_HIP(hipGetLastError());
         last_n = 0;
-        MMW_TRY(last_host.ensure((size_t)K * rank * sizeof(double)));
-        MMW_HIP(hipMemcpyAsync(last_host.p, out64.p, (size_t)K * rank * sizeof(double), hipMemcpyDeviceToHost, st));
-        MMW_HIP(hipStreamSynchronize(st));
+        last_on_host = false;
+        if (out) MMW_TRY(fetch_last((size_t)K * rank));  // (out == nullptr: the factor stays on the device until somebody reads it)
+        else MMW_HIP(hipStreamSynchronize(st));
         last_n = (size_t)K * rank;
         last_rank = rank;
         if (getenv("MMW_FACTOR_VERBOSE")) fprintf(stderr, "[factor]   export + copy-out done at %.1f ms\n", (vnow() - v_t0) * 1e3);

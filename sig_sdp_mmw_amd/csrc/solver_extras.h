@@ -158,6 +158,7 @@ template <typename T> struct Extras {
     }
     int read_factor(double* out, int64_t n) {
         if ((int64_t)fac.last_n != n || n == 0) return fail(MMW_ERR_STATE, "mmw_read_f64(FACTOR): no factor of that size has been computed");
+        MMW_TRY(fac.fetch_last(fac.last_n));
         memcpy(out, fac.last_host.p, fac.last_n * sizeof(double));
         return MMW_OK;
     }
@@ -180,10 +181,14 @@ template <typename T> struct Extras {
 
     int round(int32_t Z, int32_t Dp, const double* gX_h, int32_t nb, const double* randv_h, int32_t* z_out, int32_t* rem_out) {
         if (Z < 1 || Dp < 1 || nb < 1) return fail(MMW_ERR_ARG, "mmw_round: Z, D' and nbatch must be positive");
-        if (!gX_h || !randv_h || !z_out || !rem_out) return fail(MMW_ERR_ARG, "mmw_round: null pointer");
+        if (!randv_h || !z_out || !rem_out) return fail(MMW_ERR_ARG, "mmw_round: null pointer");
+        // gX == nullptr: the factor this handle computed last, where mmw_factor left it on the device (no copy out and in again)
+        if (!gX_h && ((size_t)K * Dp != fac.last_n || Dp != fac.last_rank || fac.last_n == 0))
+            return fail(MMW_ERR_STATE, "mmw_round: gX is null and the handle holds no factor of K x D'");
         if ((size_t)Z * sizeof(int) > 60000) return fail(MMW_ERR_ARG, "mmw_round: Z too large");
         const size_t nP = (size_t)nb * K * Z;
-        MMW_TRY(ensure(gX, (size_t)K * Dp));
+        if (gX_h) MMW_TRY(ensure(gX, (size_t)K * Dp));
+        const double* gX_d = gX_h ? gX.p : fac.out64.p;
         MMW_TRY(ensure(randv, (size_t)nb * Z * Dp));
         MMW_TRY(ensure(P, nP));
         MMW_TRY(ensure(pref, nP));
@@ -193,20 +198,20 @@ template <typename T> struct Extras {
         MMW_TRY(ensure(order, K));
         MMW_TRY(ensure(rem, nb));
         // inputs and outputs cross through the handle's page-locked staging buffer (runtime.h, PinnedBuf)
-        const size_t b_gx = (size_t)K * Dp * sizeof(double), b_rv = (size_t)nb * Z * Dp * sizeof(double);
+        const size_t b_gx = gX_h ? (size_t)K * Dp * sizeof(double) : 0, b_rv = (size_t)nb * Z * Dp * sizeof(double);
         const size_t b_z = (((size_t)nb * K * sizeof(int)) + 7) & ~(size_t)7, b_rem = (size_t)nb * sizeof(int);
         MMW_TRY(stage.ensure(b_gx + b_rv + b_z + b_rem));
         char* sp = static_cast<char*>(stage.p);
-        memcpy(sp, gX_h, b_gx);
+        if (gX_h) memcpy(sp, gX_h, b_gx);
         memcpy(sp + b_gx, randv_h, b_rv);
-        MMW_HIP(hipMemcpyAsync(gX.p, sp, b_gx, hipMemcpyHostToDevice, st));
+        if (gX_h) MMW_HIP(hipMemcpyAsync(gX.p, sp, b_gx, hipMemcpyHostToDevice, st));
         MMW_HIP(hipMemcpyAsync(randv.p, sp + b_gx, b_rv, hipMemcpyHostToDevice, st));
         MMW_HIP(hipMemsetAsync(gain.p, 0, nP * sizeof(double), st));
         MMW_HIP(hipMemsetAsync(slot.p, 0xFF, (size_t)nb * K * sizeof(int), st));
         if (kt) MMW_TRY(kt->begin(KT_PROJECT));
-        hipLaunchKernelGGL(k_row_norms_f64, dim3(grid_rows(K)), dim3(BLOCK), 0, st, K, Dp, gX.p, nrm.p);
+        hipLaunchKernelGGL(k_row_norms_f64, dim3(grid_rows(K)), dim3(BLOCK), 0, st, K, Dp, gX_d, nrm.p);
         hipLaunchKernelGGL(k_rank_desc, dim3((K + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, K, nrm.p, order.p);
-        hipLaunchKernelGGL(k_project_mfma, dim3((K + 63) / 64, (Z + 15) / 16, nb), dim3(BLOCK), 0, st, K, Z, Dp, gX.p, randv.p, P.p);
+        hipLaunchKernelGGL(k_project_mfma, dim3((K + 63) / 64, (Z + 15) / 16, nb), dim3(BLOCK), 0, st, K, Z, Dp, gX_d, randv.p, P.p);
         hipLaunchKernelGGL(k_slot_pref, dim3(K, nb), dim3(BLOCK), (size_t)Z * sizeof(double), st, K, Z, P.p, pref.p);
         if (kt) MMW_TRY(kt->end());
         MMW_HIP(hipGetLastError());

@@ -132,7 +132,10 @@ class mmw(STATS_OBJECT, sdp_solver):
         rank = int(np.min([K - 1, (Z - 1) * self.rank_radio]))
         if self.rng == "host":
             np.random.standard_normal(K)  # the start vector scipy's svds draws at mmw.py:215 (keeps seeded streams aligned)
-        X_half = solver.factor(rank, seed=dev_seed)
+        # fast path: X_half stays on the device (a DeviceFactor: an array to everything but `rounding`, which reads it in place);
+        # MMW_FACTOR_HOST=1 or rng="host" return the NumPy array itself
+        resident = self.rng == "device" and os.environ.get("MMW_FACTOR_HOST", "0") in ("", "0")
+        X_half = solver.factor(rank, seed=dev_seed, resident=resident)
         self._add_np_log("mmw_xavg", 0, np.array([Z, K, self._get_tim(tic_xavg)]))
         return True, X_half
 

@@ -96,7 +96,8 @@ class sdp_solver:
         """The `nattempt` independent attempts of sdp_solver.py:18-25 as one batch (one workgroup each); the
         first feasible one wins, like the sequential loop.  Draws all projection vectors up front, so the
         global NumPy stream is consumed differently from the reference (use round_batch=False for parity)."""
-        gX = np.ascontiguousarray(gX, dtype=np.float64)
+        if not isinstance(gX, _lib.DeviceFactor):  # (a factor still on the device is read there: no copy out and in again)
+            gX = np.ascontiguousarray(gX, dtype=np.float64)
         D = gX.shape[1]
         randv = np.random.randn(nattempt, Z, D)
         randv = randv / np.linalg.norm(randv, axis=2, keepdims=True)
@@ -112,7 +113,8 @@ class sdp_solver:
         return z_vec, Z, np.sum(not_assigned)
 
     def rounding_one_attempt(self, Z, gX, state):
-        gX = np.ascontiguousarray(gX, dtype=np.float64)
+        if not isinstance(gX, _lib.DeviceFactor):
+            gX = np.ascontiguousarray(gX, dtype=np.float64)
         D = gX.shape[1]
         randv = np.random.randn(Z, D)
         randv = randv / np.linalg.norm(randv, axis=1, keepdims=True)

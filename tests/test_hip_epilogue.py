@@ -200,3 +200,40 @@ def test_sym_eig_matches_lapack(b, kind):
     assert np.abs(np.sort(theta) - ref).max() < 1e-11 * scale * max(1, b) ** 0.5
     assert np.abs(Q.T @ Q - np.eye(b)).max() < 1e-12 * max(1, b) ** 0.5
     assert np.abs(G @ Q - Q * theta).max() < 1e-11 * scale * max(1, b) ** 0.5
+
+
+@pytest.mark.gpu
+def test_resident_factor_is_the_host_factor_and_rounds_in_place():
+    """mmw_factor(out = NULL) leaves X_half on the device, mmw_round(gX = NULL) reads it there: the same factor bit for bit, the
+    same assignment as with the array copied out and in (binary_search_relaxation.py:50-53 only hands it over); a factor somebody
+    still holds is copied out before the handle overwrites it."""
+    from sig_sdp_mmw_amd import _lib
+    from sig_sdp_mmw_amd.graphs import journal_graph
+    state = journal_graph(12, 0.02, seed=3)
+    Z, nit = 12, 30
+    s = _lib.Solver(Z, state, nit, 0.04, dtype=_lib.F32)
+    s.iterate(nit, None, seed=2)
+    rank = 2 * (Z - 1)
+    host = s.factor(rank, seed=11)
+    dev = s.factor(rank, seed=11, resident=True)
+    assert isinstance(dev, _lib.DeviceFactor) and dev.shape == host.shape and dev._host is None
+    rng = np.random.default_rng(0)
+    randv = rng.standard_normal((4, Z, rank))
+    randv /= np.linalg.norm(randv, axis=2, keepdims=True)
+    z_dev, rem_dev = s.round(Z, dev, randv)
+    assert dev._host is None  # rounded where it lies
+    z_host, rem_host = s.round(Z, host, randv)
+    assert np.array_equal(z_dev, z_host) and np.array_equal(rem_dev, rem_host)
+    assert np.array_equal(np.asarray(dev), host)
+    assert np.allclose((dev * 2.0)[3], 2.0 * host[3]) and dev.T.shape == (rank, s.K) and float(np.linalg.norm(dev)) == float(np.linalg.norm(host))
+    # the next factor overwrites the device copy: a resident one still held is copied out first
+    s.reset(nit)
+    s.iterate(nit, None, seed=3)
+    held = s.factor(rank, seed=11, resident=True)
+    newer = s.factor(rank, seed=12, resident=True)
+    assert held._host is not None and not held.on_device_of(s) and newer.on_device_of(s)
+    z_a, _ = s.round(Z, held, randv)  # goes through the host copy
+    z_b, _ = s.round(Z, np.asarray(held), randv)
+    assert np.array_equal(z_a, z_b)
+    s.close()
+    assert np.asarray(newer).shape == (s.K, rank)  # copied out when its handle went away
