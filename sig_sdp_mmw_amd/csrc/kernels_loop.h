@@ -89,7 +89,9 @@ __global__ __launch_bounds__(BLOCK) void k_dual_h(PatternDev<T> P, const T* __re
                                                   const double* __restrict__ mref = nullptr, T* __restrict__ Yun = nullptr,
                                                   T* __restrict__ wun = nullptr, double* __restrict__ sum_part = nullptr /* [4][grid] */,
                                                   const long long* __restrict__ rsfx = nullptr /* [K] */, const T* __restrict__ xval = nullptr,
-                                                  FirstVerify V = FirstVerify{}) {
+                                                  FirstVerify V = FirstVerify{}, unsigned long long* __restrict__ stamps = nullptr /* diagnostic runs */) {
+    unsigned long long tk0 = 0, tk_ptr = 0, tk_rows = 0, tk_tail = 0, tk_c = 0;
+    if (stamps) tk0 = __builtin_amdgcn_s_memtime();
     // V.plan: the last V.nwg workgroups of the launch do not take rows; they certify the first-order exponential of the iteration
     // before (kernels_mfma.h, first_verify) -- short independent work under a latency-bound pass.
     const int G = (int)gridDim.x - (V.plan ? V.nwg : 0);  // workgroups of the pass itself: the slabs' stride
@@ -124,6 +126,7 @@ __global__ __launch_bounds__(BLOCK) void k_dual_h(PatternDev<T> P, const T* __re
         const int a0 = P.indptr[rowA], a1 = P.indptr[rowA + 1];
         const int b0 = hasB ? a1 : a0, b1 = hasB ? P.indptr[rowB + 1] : a0;  // consecutive rows: B starts where A ends
         const int nmax = max(a1 - a0, b1 - b0);
+        if (stamps && nmax >= 0) tk_ptr = __builtin_amdgcn_s_memtime();  // (nmax: the row pointers have arrived)
         // the |L| row sums of an fp32 handle (they feed the exponential's norm bound, which carries a margin of 1e-3) are formed in fp32:
         // conversions, double-precision adds and cross-lane steps on these four sums were a fifth of the pass's vector instructions.
         // The violation sums stay in double: e_accu feeds the softmax, and with a large step size an fp32 sum's rounding (7e-7) was
@@ -158,6 +161,7 @@ __global__ __launch_bounds__(BLOCK) void k_dual_h(PatternDev<T> P, const T* __re
         }
         sA = wave_sum(sA);
         sB = wave_sum(sB);
+        if (stamps) tk_rows = __builtin_amdgcn_s_memtime();
         const bool tail = lane == 0 || (lane == 1 && hasB);
         if (lval) {
             laA = wave_sum(laA); ldA = wave_sum(ldA);  // exactly one lane holds a row's diagonal
@@ -186,6 +190,7 @@ __global__ __launch_bounds__(BLOCK) void k_dual_h(PatternDev<T> P, const T* __re
             }
         }
     }
+    if (stamps) tk_tail = __builtin_amdgcn_s_memtime();
     const double invK = 1.0 / (double)K, Zm1 = (double)(Z - 1), denF = 1.0 / ((double)K * Zm1) + 0.5;
     for (int c = blockIdx.x * BLOCK + threadIdx.x; c < baseH; c += G * BLOCK) {
         T et;
@@ -203,6 +208,7 @@ __global__ __launch_bounds__(BLOCK) void k_dual_h(PatternDev<T> P, const T* __re
             else sF += (double)ex;
         }
     }
+    if (stamps) tk_c = __builtin_amdgcn_s_memtime();
     // one LDS round for everything the block hands on: {max e_accu | L sums sd, pp, pm | softmax sums sD, sF, sH, sW}
     __shared__ double shr[8][WAVES_PER_BLOCK];
     best = wave_max(best);
@@ -222,6 +228,11 @@ __global__ __launch_bounds__(BLOCK) void k_dual_h(PatternDev<T> P, const T* __re
         if (q == 0) max_part[blockIdx.x] = t;
         else if (q < 4) { if (lval) lpart[(q - 1) * G + blockIdx.x] = t; }
         else if (mref) sum_part[(q - 4) * G + blockIdx.x] = t;
+    }
+    if (stamps && lane == 0) {  // per wave: start, pointers, rows summed, rows' tails done, violation part done, end
+        const unsigned long long te = __builtin_amdgcn_s_memtime();
+        unsigned long long* o = stamps + ((size_t)blockIdx.x * WAVES_PER_BLOCK + wib) * 8;
+        o[0] = tk0; o[1] = tk_ptr; o[2] = tk_rows; o[3] = tk_tail; o[4] = tk_c; o[5] = te;
     }
 }
 

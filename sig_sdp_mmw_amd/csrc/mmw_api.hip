@@ -1136,9 +1136,10 @@ template <typename T> struct Solver final : mmw_solver {
             MMW_TRY(settle());
             // ... or as many as the last settled plan's estimate leaves room for (room_iterations)
             int cap = lagged_ok() ? std::max(8, std::min(32, age())) : std::max(4, std::min(32, age() / 2));
-            // (the room is an extrapolation: before two plans of this run have shown how fast the matrix grows, a chunk does not reach
-            // further than the run is old -- at slot counts near infeasibility the norm grew 16x over iterations 4..35, not the 9x of a linear law)
-            if (chain_ok && age() >= 4) cap = std::max(cap, std::min(age_prev >= 0 ? 32 : std::max(8, age()), room_iterations()));
+            // (holding the chunk to the run's age until two plans have shown how fast the matrix grows would spare the hard probes of a
+            // bisection one discarded chunk -- at slot counts near infeasibility the norm grew 16x over iterations 4..35, not the 9x of a
+            // linear law -- but costs every run one more readback in its first 32 iterations: measured, not kept)
+            if (chain_ok && age() >= 4) cap = std::max(cap, std::min(32, room_iterations()));
             if (warm_fresh) cap = 8;
             int chunk = std::min(left, cap);
             if (left - chunk == 1) ++chunk;  // no trailing chunk of one iteration: it would run synchronously and break the chain of chunks
@@ -1305,9 +1306,50 @@ template <typename T> struct Solver final : mmw_solver {
             if (fused_dual) {
                 ++n_fused_iters;
                 if (yun.n < (size_t)C) MMW_TRY(yun.alloc((size_t)C));
+                // MMW_DUAL_STAMPS=1 (developer aid): per-wave phase clocks of the last iteration's launch, printed to stderr
+                DevBuf<unsigned long long> dh_stamps;
+                const bool want_dst = it + 1 == n && getenv("MMW_DUAL_STAMPS") != nullptr;
+                if (want_dst) {
+                    MMW_TRY(dh_stamps.alloc((size_t)gd * WAVES_PER_BLOCK * 8));
+                    MMW_HIP(hipMemsetAsync(dh_stamps.p, 0, (size_t)gd * WAVES_PER_BLOCK * 8 * sizeof(unsigned long long), st));
+                }
                 hipLaunchKernelGGL((k_dual_h<T>), dim3(gd), dim3(BLOCK), 0, st, P, rsum.p, e_this.p, e_accu.p, eta, max_part.p,
                                    (const T*)(lagged_it ? lval.p : nullptr), 0.5, eng.row_part.p, (const double*)(scal.p + 4), yun.p, wH.p, sum_part.p,
-                                   rs_it, xcur);
+                                   rs_it, xcur, FirstVerify{}, dh_stamps.p);
+                if (want_dst) {
+                    std::vector<unsigned long long> h((size_t)gd * WAVES_PER_BLOCK * 8);
+                    MMW_HIP(hipMemcpyAsync(h.data(), dh_stamps.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+                    MMW_HIP(hipStreamSynchronize(st));
+                    double sum[5] = {0}, slow[5] = {0};
+                    unsigned long long t0 = ~0ull, t1 = 0;
+                    std::vector<std::pair<unsigned long long, size_t>> byl;
+                    int nw = 0;
+                    for (size_t w = 0; w < h.size() / 8; ++w) {
+                        const unsigned long long* q = &h[w * 8];
+                        if (!q[5]) continue;
+                        ++nw;
+                        const unsigned long long p1 = q[1] ? q[1] : q[0], p2 = q[2] ? q[2] : p1, p3 = q[3], p4 = q[4];
+                        sum[0] += (double)(p1 - q[0]); sum[1] += (double)(p2 - p1); sum[2] += (double)(p3 - p2); sum[3] += (double)(p4 - p3); sum[4] += (double)(q[5] - p4);
+                        t0 = std::min(t0, q[0]); t1 = std::max(t1, q[5]);
+                        byl.push_back({q[5] - q[0], w});
+                    }
+                    std::sort(byl.rbegin(), byl.rend());
+                    const size_t top = std::max<size_t>(1, byl.size() / 20);
+                    unsigned long long late = 0;
+                    for (size_t i = 0; i < top && i < byl.size(); ++i) {
+                        const unsigned long long* q = &h[byl[i].second * 8];
+                        const unsigned long long p1 = q[1] ? q[1] : q[0], p2 = q[2] ? q[2] : p1;
+                        slow[0] += (double)(p1 - q[0]); slow[1] += (double)(p2 - p1); slow[2] += (double)(q[3] - p2); slow[3] += (double)(q[4] - q[3]); slow[4] += (double)(q[5] - q[4]);
+                        late = std::max(late, q[0] - t0);
+                    }
+                    unsigned long long last_start = 0;
+                    for (size_t w = 0; w < h.size() / 8; ++w) if (h[w * 8 + 5]) last_start = std::max(last_start, h[w * 8] - t0);
+                    if (nw)
+                        fprintf(stderr, "[dual stamps] %d workgroups, %d waves; clocks per wave: row pointers %.0f, rows (entries + gathers + sums) %.0f, rows' tails %.0f, violation part %.0f, fold + stores %.0f; "
+                                        "slowest twentieth: %.0f / %.0f / %.0f / %.0f / %.0f; first start to last end %.0f, last wave started at %.0f\n",
+                                gd, nw, sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[3] / nw, sum[4] / nw, slow[0] / top, slow[1] / top, slow[2] / top, slow[3] / top, slow[4] / top,
+                                (double)(t1 - t0), (double)last_start);
+                }
                 hipLaunchKernelGGL(k_dual_scal, dim3(1 + fv.nwg), dim3(DSCAL_THREADS), 0, st, sum_part.p, max_part.p, gd, scal.p,
                                    dual_gap, eng.viol_d.p, fv);
             } else {
