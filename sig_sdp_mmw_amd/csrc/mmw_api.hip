@@ -85,6 +85,7 @@ template <typename T> struct Solver final : mmw_solver {
     DevBuf<T> lval_blk;
     bool lblk_stale = false;         // lval_blk lags lval (the matrix-core kernel ran the last products)
     bool lagged_plan = getenv("MMW_NO_LAGGED_PLAN") == nullptr;
+    bool lagged_missed = false;  // an extrapolated plan of this run did not cover its matrix: the run's matrix outgrows the extrapolation, exact plans until the next reset
     DevBuf<ExpmPlan> sn_plan;        // plan (with its history) at the start of the pending chunk
     DevBuf<int> b_kbase, b_fpos, b_mdesc, b_munfixed, b_morder;  // matrix-core SpMM: its row blocks, CSR entry -> fragment image position
     DevBuf<unsigned> afrag;          // the matrix as bf16 hi << 16 | lo words in MFMA fragment order
@@ -903,6 +904,7 @@ template <typename T> struct Solver final : mmw_solver {
         age0 += iter;
         iter = 0;
         warm_fresh = true;
+        lagged_missed = false;
         age_prev = age_last = -1;
         pending = false;
         chain_ok = false;
@@ -928,6 +930,7 @@ template <typename T> struct Solver final : mmw_solver {
         pending = false;
         chain_ok = false;
         plan_seen = false;
+        lagged_missed = false;
         m_guess = 3;
         if (eng.viol_d.p) MMW_TRY(eng.clear_violation());
         MMW_TRY(eng.reset_plan_history(false));
@@ -1091,6 +1094,7 @@ template <typename T> struct Solver final : mmw_solver {
         }
         ++replays;
         const bool operands_only = (viol & VIOL_OPERANDS) && !first_guess;  // the bf16 split's gate: the fp32 kernel has to take over
+        if (viol & VIOL_LAGGED) lagged_missed = true;  // (er-50k: a second chunk missed the same way 32 iterations later)
         say_replay(viol, "discarded");
         MMW_TRY(restore_pending());
         if (cautious_replay && !operands_only && eng.method == MMW_EXPM_LANCZOS && pend_n > 1) {
@@ -1225,7 +1229,7 @@ template <typename T> struct Solver final : mmw_solver {
     // the exact one, which must not cost a second product: on graphs without locality a product is 10x the two kernels saved).
     bool lagged_ok() const {
         const ExpmPlan& p = eng.last;
-        if (!lagged_plan || !p.apost || p.m_eff != 1) return false;
+        if (!lagged_plan || lagged_missed || !p.apost || p.m_eff != 1) return false;
         union { unsigned u; float f; } e;
         e.u = p.conv[1];
         return (double)e.f <= p.tol / 2.0;
