@@ -151,6 +151,9 @@ template <typename T> struct Solver final : mmw_solver {
     size_t pend_events0 = 0;  // phase-timer events recorded before the pending chunk
     uint64_t pend_seed = 0;
     int replays = 0;
+    DevBuf<double> emax_d;
+    double emax_h = 0.0;
+    int emax_enq_iter = -1, emax_iter = -1;  // iteration count the enqueued / fetched maximum violation belongs to
     bool exact_plans_only = false;  // a cautious second attempt at a discarded chunk is running (settle)
     const bool cautious_replay = !(getenv("MMW_CAUTIOUS_REPLAY") && atoi(getenv("MMW_CAUTIOUS_REPLAY")) == 0);
     ExpmEngine<T> eng;
@@ -903,6 +906,7 @@ template <typename T> struct Solver final : mmw_solver {
         nit = nit_;
         age0 += iter;
         iter = 0;
+        emax_enq_iter = emax_iter = -1;
         warm_fresh = true;
         lagged_missed = false;
         age_prev = age_last = -1;
@@ -924,6 +928,7 @@ template <typename T> struct Solver final : mmw_solver {
         if (nit_ < 1) return fail(MMW_ERR_ARG, "nit must be >= 1");
         nit = nit_;
         iter = 0;
+        emax_enq_iter = emax_iter = -1;
         age0 = 0;
         warm_fresh = false;
         age_prev = age_last = -1;
@@ -1061,6 +1066,7 @@ template <typename T> struct Solver final : mmw_solver {
     // feasibility: the matrix grows faster than any history predicts) took 3 replays per 150 iterations, 29 ms instead of 13.
     int restore_pending() {
         chain_ok = false;
+        emax_enq_iter = emax_iter = -1;  // (the reduction enqueued behind the discarded chunk saw its e_this)
         MMW_TRY(eng.clear_violation());
         MMW_TRY(copy_state(false));
         iter = pend_iter0;
@@ -1128,7 +1134,8 @@ template <typename T> struct Solver final : mmw_solver {
         const bool optimistic = randv == nullptr && n > 1 && !kt_exact() && !getenv("MMW_SYNC_PLAN");  // profiling mode 1 counts exact launches
         if (!optimistic) {
             chain_ok = false;
-            return iterate_impl(n, randv, seed, false);
+            MMW_TRY(iterate_impl(n, randv, seed, false));
+            return enqueue_emax();
         }
         // Chunks enqueued without plan readbacks.  Each chunk starts from a device snapshot; before the next one starts the
         // plan of the previous is looked at (one sync): a chunk that needed more steps than were launched is restored and
@@ -1162,6 +1169,19 @@ template <typename T> struct Solver final : mmw_solver {
             pending = chunk > 1;
             left -= chunk;
         }
+        return enqueue_emax();
+    }
+    // The objective record's one number -- the largest violation of the last iteration (MMW_F_E_MAX) -- is reduced right behind the call's
+    // work and copied out by the mmw_sync that waits for it anyway: reading it afterwards is free (its launch + copy + wait were a third
+    // of what a 20-step timed region spends on its record).  A replay of the last chunk changes `iter` back and forth but ends at the same
+    // e_this only after re-running, so the value is tied to the iteration count AND dropped whenever a chunk is discarded.
+    int enqueue_emax() {
+        if (iter <= 0) return MMW_OK;
+        if (!emax_d.p) MMW_TRY(emax_d.alloc(1));
+        hipLaunchKernelGGL((k_max_of<T>), dim3(1), dim3(1024), 0, st, (size_t)H.C(), e_this.p, emax_d.p);
+        MMW_HIP(hipGetLastError());
+        emax_enq_iter = iter;
+        emax_iter = -1;
         return MMW_OK;
     }
     // Steps to launch without reading the plan back: what the last application used, plus one spare step unless its
@@ -1617,7 +1637,10 @@ template <typename T> struct Solver final : mmw_solver {
         if (host_only) return fail(MMW_ERR_STATE, "this handle was created with device -1 (host pattern only)");
         MMW_HIP(hipSetDevice(device));
         MMW_TRY(settle());
+        const bool want_emax = emax_enq_iter == iter && emax_iter != iter && emax_d.p != nullptr;
+        if (want_emax) MMW_HIP(hipMemcpyAsync(&emax_h, emax_d.p, sizeof(double), hipMemcpyDeviceToHost, st));
         MMW_HIP(hipStreamSynchronize(st));
+        if (want_emax) emax_iter = iter;
         MMW_TRY(kt.flush());
         return flush_events();
     }
@@ -1673,6 +1696,10 @@ template <typename T> struct Solver final : mmw_solver {
             case MMW_F_E_THIS: return export_T(e_this.p, C, out, n);
             case MMW_F_E_MAX: {
                 if (n != 1) return fail(MMW_ERR_ARG, "the maximum violation is one number");
+                if (emax_iter == iter && emax_iter >= 0) {  // reduced behind the last mmw_iterate's work and fetched by mmw_sync
+                    out[0] = emax_h;
+                    return MMW_OK;
+                }
                 hipLaunchKernelGGL((k_max_of<T>), dim3(1), dim3(1024), 0, st, C, e_this.p, out64.p);
                 MMW_HIP(hipGetLastError());
                 return copy_d2h(out, out64.p, sizeof(double), st);

@@ -264,6 +264,17 @@ def test_max_violation_field_is_the_maximum_of_e_this():
     a.iterate(6, None, seed=4)
     assert a.read(_lib.F_E_MAX)[0] == np.max(a.read(_lib.F_E_THIS))
     a.close()
+    # the value mmw_sync fetched behind the run (no device work at the read) is the same number, also across a reset and a replayed chunk
+    b = _lib.Solver(10, state, 40, 0.05, dtype=_lib.F32)
+    for rounds in range(2):
+        b.iterate(25, None, seed=4)
+        b.sync()
+        assert b.read(_lib.F_E_MAX)[0] == np.max(b.read(_lib.F_E_THIS))
+        b.iterate(15, None, seed=4)
+        b.sync()
+        assert b.read(_lib.F_E_MAX)[0] == np.max(b.read(_lib.F_E_THIS))
+        b.reset(40)
+    b.close()
 
 
 @pytest.mark.parametrize("dtype,tol", [(_lib.F32, 2e-5), (_lib.F64, 1e-9)])
