@@ -444,7 +444,10 @@ template <typename T> struct Factorizer {
             // Matrix-core products (two-half bf16 split, error <= 2.3e-5 || |A| || per product) serve the filter while the last
             // residual says that at least two more passes follow: the subspace error they leave is far below what those passes
             // start from, and every Rayleigh-Ritz product and the last passes run on the fp32 kernel.
-            static const double mf_floor = getenv("MMW_FACTOR_MF_FLOOR") ? atof(getenv("MMW_FACTOR_MF_FLOOR")) : 100.0;
+            // (floor: 100 x tol until the end of round 3; with 3 x tol the passes end on the same residuals to three digits -- 8.1e-6 / 1.20e-5 /
+            // 1.42e-5 / 5.07e-7 at ranks 370 / 208 / 128 / 88 of the benchmark's probes -- in the same number of passes, 2 ms sooner per call;
+            // below 1 x tol the last residuals stall at 2.6e-6 instead of 5e-7, the split's own floor)
+            static const double mf_floor = getenv("MMW_FACTOR_MF_FLOOR") ? atof(getenv("MMW_FACTOR_MF_FLOOR")) : 3.0;
             const bool mf_stage = mf_use && (outer == 0 || last_resid > mf_floor * tol);
             const bool no_rr_next = rr_skip > 0 && b < K;
             // ---- Rayleigh-Ritz on span(V)
