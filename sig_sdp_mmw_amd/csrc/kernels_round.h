@@ -24,17 +24,23 @@ __global__ __launch_bounds__(BLOCK) void k_row_norms_f64(int K, int Dp, const do
 
 // ---- order = argsort(-key): rank by counting, ties by lower index (stable) --------------------
 // rank[k] = #{ j : key[j] > key[k]  or (key[j] == key[k] and j < k) };  order[rank[k]] = k
-__global__ __launch_bounds__(BLOCK) void k_rank_desc(int n, const double* __restrict__ key, int* __restrict__ order) {
+// From the whole chip: the K^2 comparisons are split into RANK_SPLIT groups of key tiles (grid.y), every workgroup leaves its partial
+// counts, and the second launch adds them (fixed order, integers) and scatters.  (One workgroup per 256 keys walking all K keys -- 40
+// workgroups at K = 10 003 -- took 0.70 ms, a tenth of a rounding call.)
+constexpr int RANK_SPLIT = 16;
+__global__ __launch_bounds__(BLOCK) void k_rank_count(int n, const double* __restrict__ key, int* __restrict__ part /* [RANK_SPLIT][n] */) {
     __shared__ double tile[BLOCK];
     const int k = blockIdx.x * BLOCK + threadIdx.x;
     const double mine = k < n ? key[k] : 0.0;
+    const int ntiles = (n + BLOCK - 1) / BLOCK, per = (ntiles + RANK_SPLIT - 1) / RANK_SPLIT;
+    const int t_beg = (int)blockIdx.y * per, t_end = min(ntiles, t_beg + per);
     int r = 0;
-    for (int j0 = 0; j0 < n; j0 += BLOCK) {
-        const int j = j0 + threadIdx.x;
+    for (int tl = t_beg; tl < t_end; ++tl) {
+        const int j0 = tl * BLOCK, j = j0 + (int)threadIdx.x;
         tile[threadIdx.x] = j < n ? key[j] : 0.0;
         __syncthreads();
         const int lim = n - j0 < BLOCK ? n - j0 : BLOCK;
-        if (lim == BLOCK) {  // whole tile: sixteen LDS reads in flight per trip (one wave per SIMD here: a dependent read per step was 0.7 ms at K = 10 k)
+        if (lim == BLOCK) {
 #pragma unroll 16
             for (int t = 0; t < BLOCK; ++t) {
                 const double o = tile[t];
@@ -47,7 +53,15 @@ __global__ __launch_bounds__(BLOCK) void k_rank_desc(int n, const double* __rest
         }
         __syncthreads();
     }
-    if (k < n) order[r] = k;
+    if (k < n) part[(size_t)blockIdx.y * n + k] = r;
+}
+__global__ __launch_bounds__(BLOCK) void k_rank_scatter(int n, const int* __restrict__ part, int* __restrict__ order) {
+    const int k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= n) return;
+    int r = 0;
+#pragma unroll
+    for (int s = 0; s < RANK_SPLIT; ++s) r += part[(size_t)s * n + k];
+    order[r] = k;
 }
 
 // ---- projection on the fp64 matrix cores -------------------------------------------------------

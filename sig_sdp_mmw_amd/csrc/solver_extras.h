@@ -17,7 +17,7 @@ template <typename T> struct Extras {
     DevBuf<double> so_data, h_max, so_hmax;  // so_hmax[e] = h_max[so_indices[e]]: the greedy reads it like so_data
     DevBuf<GreedyHdr> ghdr;
     DevBuf<double> gX, randv, P, gain, nrm;
-    DevBuf<int> pref, slot, order, rem, glag;
+    DevBuf<int> pref, slot, order, rem, glag, rank_part;
     Factorizer<T> fac;
     // gap work
     DevBuf<T> g_x, g_l, g_y, g_e1, g_e2, g_r, g_vec, g_tm;
@@ -176,6 +176,7 @@ template <typename T> struct Extras {
         MMW_TRY(ensure(P, nP)); MMW_TRY(ensure(pref, nP)); MMW_TRY(ensure(gain, nP));
         MMW_TRY(ensure(slot, (size_t)nb * K_)); MMW_TRY(ensure(nrm, K_)); MMW_TRY(ensure(order, K_)); MMW_TRY(ensure(rem, nb));
         MMW_TRY(ensure(glag, (size_t)K_));
+        MMW_TRY(ensure(rank_part, (size_t)RANK_SPLIT * K_));
         return MMW_OK;
     }
 
@@ -196,6 +197,7 @@ template <typename T> struct Extras {
         MMW_TRY(ensure(slot, (size_t)nb * K));
         MMW_TRY(ensure(nrm, K));
         MMW_TRY(ensure(order, K));
+        MMW_TRY(ensure(rank_part, (size_t)RANK_SPLIT * K));
         MMW_TRY(ensure(rem, nb));
         // inputs and outputs cross through the handle's page-locked staging buffer (runtime.h, PinnedBuf)
         const size_t b_gx = gX_h ? (size_t)K * Dp * sizeof(double) : 0, b_rv = (size_t)nb * Z * Dp * sizeof(double);
@@ -210,7 +212,8 @@ template <typename T> struct Extras {
         MMW_HIP(hipMemsetAsync(slot.p, 0xFF, (size_t)nb * K * sizeof(int), st));
         if (kt) MMW_TRY(kt->begin(KT_PROJECT));
         hipLaunchKernelGGL(k_row_norms_f64, dim3(grid_rows(K)), dim3(BLOCK), 0, st, K, Dp, gX_d, nrm.p);
-        hipLaunchKernelGGL(k_rank_desc, dim3((K + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, K, nrm.p, order.p);
+        hipLaunchKernelGGL(k_rank_count, dim3((K + BLOCK - 1) / BLOCK, RANK_SPLIT), dim3(BLOCK), 0, st, K, nrm.p, rank_part.p);
+        hipLaunchKernelGGL(k_rank_scatter, dim3((K + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, K, (const int*)rank_part.p, order.p);
         hipLaunchKernelGGL(k_project_mfma, dim3((K + 63) / 64, (Z + 15) / 16, nb), dim3(BLOCK), 0, st, K, Z, Dp, gX_d, randv.p, P.p);
         hipLaunchKernelGGL(k_slot_pref, dim3(K, nb), dim3(BLOCK), (size_t)Z * sizeof(double), st, K, Z, P.p, pref.p);
         if (kt) MMW_TRY(kt->end());
