@@ -1514,7 +1514,6 @@ template <typename T> struct Solver final : mmw_solver {
                         MMW_HIP(hipMemcpyAsync(h.data(), sdm_stamps.p, n_st * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
                         MMW_HIP(hipStreamSynchronize(st));
                         double sum[8] = {0}, life_max = 0;
-                        unsigned long long tmin = ~0ull, tmax = 0;
                         int nw = 0;
                         for (size_t w = 0; w < n_st / 8; ++w) {
                             const unsigned long long* q = &h[w * 8];
@@ -1522,8 +1521,6 @@ template <typename T> struct Solver final : mmw_solver {
                             ++nw;
                             for (int k = 0; k < 8; ++k) sum[k] += (double)q[k];
                             life_max = std::max(life_max, (double)q[4]);
-                            tmin = std::min(tmin, q[6]);
-                            tmax = std::max(tmax, q[6] + q[4]);
                         }
                         {   // the slowest twentieth of the waves: where their time went
                             std::vector<std::pair<unsigned long long, size_t>> byl;
@@ -1542,8 +1539,8 @@ template <typename T> struct Solver final : mmw_solver {
                         }
                         if (nw)
                             fprintf(stderr, "[sddmm stamps] grid %u x %u, %d working waves; shader clocks per wave: prologue %.0f, wait+barrier %.0f, issue %.0f, reads+products %.0f, "
-                                            "row/column sums %.0f, tile+stores+atomics %.0f, lifetime %.0f (max %.0f), first start to last end %.0f\n",
-                                    grid.x, grid.y, nw, sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[3] / nw, sum[5] / nw, sum[7] / nw, sum[4] / nw, life_max, (double)(tmax - tmin));
+                                            "row/column sums %.0f, tile+stores+atomics %.0f, lifetime %.0f (max %.0f)\n",
+                                    grid.x, grid.y, nw, sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[3] / nw, sum[5] / nw, sum[7] / nw, sum[4] / nw, life_max);
                     }
                     sd_done = true;
                     // (MMW_FV_IN_SDDMM=0: certified by spare workgroups of the next iteration's DUAL phase, or by a launch of its own after the chunk's last)
