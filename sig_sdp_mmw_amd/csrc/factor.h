@@ -96,9 +96,18 @@ template <typename T> struct DenseWork {
     // G = V^T W  (b x b)
     int gram(int K, int b, int ld, const T* V, const T* W, bool sym) {
         int nslice, rps;
-        gram_geometry(K, b, nslice, rps);
         MMW_TRY(ensure(b, 16));
-        hipLaunchKernelGGL((k_gram<T>), dim3((b + 63) / 64, (b + 15) / 16, nslice), dim3(WAVE), 0, st, K, b, ld, V, W, rps, Gpart.p);
+        static const bool old_gram = getenv("MMW_GRAM_WAVES") != nullptr;  // (the one-wave-per-tile kernel, for comparison)
+        if (old_gram) {
+            gram_geometry(K, b, nslice, rps);
+            hipLaunchKernelGGL((k_gram<T>), dim3((b + 63) / 64, (b + 15) / 16, nslice), dim3(WAVE), 0, st, K, b, ld, V, W, rps, Gpart.p);
+        } else {
+            const int tiles = ((b + 63) / 64) * ((b + 63) / 64);
+            nslice = std::max(1, std::min(16, (768 + tiles - 1) / tiles));
+            rps = ((K + nslice - 1) / nslice + GR_ROWS - 1) / GR_ROWS * GR_ROWS;
+            nslice = (K + rps - 1) / rps;
+            hipLaunchKernelGGL((k_gram_tiles<T>), dim3((b + 63) / 64, (b + 63) / 64, nslice), dim3(BLOCK), 0, st, K, b, ld, V, W, rps, Gpart.p);
+        }
         hipLaunchKernelGGL(k_gram_reduce, dim3(grid_elems((size_t)b * b)), dim3(BLOCK), 0, st, b, nslice, Gpart.p, G.p, sym ? 1 : 0);
         MMW_HIP(hipGetLastError());
         return MMW_OK;

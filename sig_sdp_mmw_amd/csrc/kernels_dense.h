@@ -51,6 +51,64 @@ __global__ __launch_bounds__(WAVE) void k_gram(int K, int b, int ld, const T* __
             if (i < b && j < b) G[(size_t)i * b + j] = acc[n][q];
         }
 }
+// The same product from LDS tiles: a workgroup of four waves owns a 64 x 64 tile of G for one slice of rows and walks the rows 16 at a
+// time -- every thread brings 16 bytes of V and of W per stage (a row's 64 columns are one 256-byte run), double-buffered, and wave w
+// multiplies its 16 columns of V with the tile's 64 columns of W exactly as k_gram does.  k_gram's one wave per 16 x 64 tile fetched
+// its operands in 64-byte runs, one row per lane group, W once per 16 rows of G: 627 MB of 64-byte requests per call at b = 444
+// (418 us, 9 TFLOP/s); here 250 MB in 256-byte runs.  Row stride 80 floats in LDS: the four k-rows of a fragment read fall on four
+// different 16-bank groups.
+constexpr int GR_ROWS = 16, GR_LD = 80;
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_gram_tiles(int K, int b, int ld, const T* __restrict__ V, const T* __restrict__ W,
+                                                     int rows_per_slice, double* __restrict__ Gpart) {
+    __shared__ T sV[2][GR_ROWS][GR_LD], sW[2][GR_ROWS][GR_LD];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 64, sl = blockIdx.z;
+    const int r_beg = sl * rows_per_slice, r_end = min(K, r_beg + rows_per_slice);
+    const int li = lane & 15, lk = lane >> 4;
+    const int tr = threadIdx.x >> 4, tc = (threadIdx.x & 15) * 4;  // this thread's row of a stage and its four columns
+    d4 acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = (d4){0.0, 0.0, 0.0, 0.0};
+    T rv[4], rw[4];
+    auto fetch = [&](int r0) {
+        const int row = r0 + tr;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            rv[q] = (row < r_end && i0 + tc + q < b) ? V[(size_t)row * ld + i0 + tc + q] : T(0);
+            rw[q] = (row < r_end && j0 + tc + q < b) ? W[(size_t)row * ld + j0 + tc + q] : T(0);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { sV[buf][tr][tc + q] = rv[q]; sW[buf][tr][tc + q] = rw[q]; }
+    };
+    fetch(r_beg);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int r = r_beg; r < r_end; r += GR_ROWS) {
+        const bool more = r + GR_ROWS < r_end;
+        if (more) fetch(r + GR_ROWS);  // in flight under this stage's products
+#pragma unroll
+        for (int kk = 0; kk < GR_ROWS; kk += 4) {
+            const double a = (double)sV[buf][kk + lk][16 * wv + li];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, (double)sW[buf][kk + lk][16 * n + li], acc[n], 0, 0, 0);
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    double* G = Gpart + (size_t)sl * b * b;
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + 16 * wv + lk + 4 * q, j = j0 + n * 16 + li;
+            if (i < b && j < b) G[(size_t)i * b + j] = acc[n][q];
+        }
+}
 // G = sum over slices, optionally symmetrised
 __global__ __launch_bounds__(BLOCK) void k_gram_reduce(int b, int nslice, const double* __restrict__ Gpart, double* __restrict__ G,
                                                        int symmetrise) {

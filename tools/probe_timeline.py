@@ -17,7 +17,7 @@ print("create %.1f ms" % ((time.perf_counter() - t0) * 1e3))
 s.set_expm(_lib.EXPM_LANCZOS, 12, 1e-6)
 def T():
     return time.perf_counter()
-for rep, Z in enumerate([186, 105, 65, 45, 35, 40]):
+for rep, Z in enumerate([int(z) for z in os.environ.get("ZS", "186,105,65,45,35,40").split(",")]):
     a = T(); s.set_slots(Z, 150); s.sync(); b = T()
     s.set_timing(int(os.environ.get("STRIDE", "8")))
     s.iterate(150, None, seed=77 + rep); c = T()
