@@ -482,7 +482,15 @@ template <typename T> struct Factorizer {
                 hipLaunchKernelGGL(k_set_eye, dim3(grid_elems((size_t)b * b)), dim3(BLOCK), 0, st, b, dw.Q.p);
                 hipLaunchKernelGGL(k_get_diag, dim3(grid_elems(b)), dim3(BLOCK), 0, st, b, dw.G.p, dw.diag.p);
             } else {
-                MMW_TRY(dw.jacobi(b, f32 ? 1e-8 : 1e-13, 30));
+                // The eigensolve only has to be as sharp as the subspace is: what it leaves off the diagonal mixes Ritz pairs whose residuals are
+                // still `last_resid`, so 1e-2 of that (never looser than 1e-4, never tighter than the final 1e-8 / 1e-13; the residuals that decide are true residuals of the rotated vectors) costs the residual
+                // estimate nothing and the block Jacobi a sweep or two per call (b = 444: a sweep is 13 block rounds of two launches).
+                static const bool jac_fixed = getenv("MMW_FACTOR_JACOBI_FIXED") != nullptr;
+                const double jac_fin = f32 ? 1e-8 : 1e-13;
+                static const double jac_rel = getenv("MMW_FACTOR_JACOBI_REL") ? atof(getenv("MMW_FACTOR_JACOBI_REL")) : 1e-2;
+                static const double jac_cap = getenv("MMW_FACTOR_JACOBI_CAP") ? atof(getenv("MMW_FACTOR_JACOBI_CAP")) : 1e-4;
+                const double jac_tol = (jac_fixed || outer == 0 || !(last_resid > 0.0)) ? jac_fin : std::max(jac_fin, std::min(jac_cap, jac_rel * last_resid));
+                MMW_TRY(dw.jacobi(b, jac_tol, 30));
             }
             MMW_HIP(hipMemcpyAsync(theta.data(), dw.diag.p, b * sizeof(double), hipMemcpyDeviceToHost, st));
             MMW_HIP(hipStreamSynchronize(st));
