@@ -446,6 +446,7 @@ template <typename T> struct Factorizer {
         int outer = 0;
         bool done = false;
         double prev_resid = -1.0;
+        bool mf_stalled = false, mf_last_pass = false;  // the matrix-core split stopped paying / the pass before this residual ran on it
         int degree = 12;  // filter degree schedule 12, 30, 40, 40, ...: few Rayleigh-Ritz / orthonormalisation rounds
         int rr_skip = 0;  // filter passes still to run before the next Rayleigh-Ritz
         bool skip_rr = false;
@@ -454,10 +455,12 @@ template <typename T> struct Factorizer {
             // residual says that at least two more passes follow: the subspace error they leave is far below what those passes
             // start from, and every Rayleigh-Ritz product and the last passes run on the fp32 kernel.
             // (floor: 100 x tol until the end of round 3; with 3 x tol the passes end on the same residuals to three digits -- 8.1e-6 / 1.20e-5 /
-            // 1.42e-5 / 5.07e-7 at ranks 370 / 208 / 128 / 88 of the benchmark's probes -- in the same number of passes, 2 ms sooner per call;
-            // below 1 x tol the last residuals stall at 2.6e-6 instead of 5e-7, the split's own floor)
-            static const double mf_floor = getenv("MMW_FACTOR_MF_FLOOR") ? atof(getenv("MMW_FACTOR_MF_FLOOR")) : 3.0;
-            const bool mf_stage = mf_use && (outer == 0 || last_resid > mf_floor * tol);
+            // 1.42e-5 / 5.07e-7 at ranks 370 / 208 / 128 / 88 of the benchmark's probes -- in the same number of passes, 2 ms sooner per call.
+            // With 1 x tol -- every filter pass there is, since a pass runs only while the residual is above the tolerance -- the last
+            // residuals end at 2.6e-6 instead of 5e-7: the split's own floor, an eighth of the tolerance, and the last pass of the small
+            // ranks costs half.  A pass on the matrix cores that does not halve a residual below 100 x tol sends the rest to the fp32 kernel.)
+            static const double mf_floor = getenv("MMW_FACTOR_MF_FLOOR") ? atof(getenv("MMW_FACTOR_MF_FLOOR")) : 1.0;
+            const bool mf_stage = mf_use && !mf_stalled && (outer == 0 || last_resid > mf_floor * tol);
             const bool no_rr_next = rr_skip > 0 && b < K;
             // ---- Rayleigh-Ritz on span(V)
             if (mf_stage && no_rr_next) {  // this product only feeds the filter
@@ -521,6 +524,7 @@ template <typename T> struct Factorizer {
             }
             const double scale_top = std::max(std::fabs(theta[0]), 1e-300);
             last_resid = worst / scale_top;
+            if (mf_last_pass && prev_resid > 0.0 && last_resid < 100.0 * tol && last_resid > 0.5 * prev_resid) mf_stalled = true;
             if (getenv("MMW_FACTOR_VERBOSE")) fprintf(stderr, "[factor]   outer %d degree %d resid %.2e at %.1f ms\n", outer, degree, last_resid, (vnow() - v_t0) * 1e3);
             if (!skip_rr && (b >= K || last_resid <= tol)) {
                 done = true;
@@ -537,7 +541,8 @@ template <typename T> struct Factorizer {
             const double a0 = skip_rr ? rho * rho : std::max(mu_top, rho * rho * 1e-30);  // no Ritz values yet: the 1-norm bounds the spectrum
             double sigma1 = e / (a0 - cen), sigma = sigma1;
             // Y = sigma1/e (B V - cen V): T1 = A V (already W); Ycur = c1 * A W + c2 * V
-            const bool mf_pass = mf_stage && (no_rr || last_resid > mf_floor * tol || skip_rr);  // this pass's residual is known by now
+            const bool mf_pass = mf_stage && !mf_stalled && (no_rr || last_resid > mf_floor * tol || skip_rr);  // this pass's residual is known by now
+            mf_last_pass = mf_pass;
             if (mf_pass) {
                 if (!(mf_stage && no_rr)) MMW_TRY(split(W.p));  // W came from the fp32 kernel (or was rotated by the Rayleigh-Ritz step)
                 MMW_TRY((spmm_mf<SPMM_AXPBY>(ld, W.p, Y1.p, V.p, V.p, ascale * sigma1 / e, -cen * sigma1 / e, 0.0)));
