@@ -17,7 +17,9 @@ template <typename T> struct Extras {
     DevBuf<double> so_data, h_max, so_hmax;  // so_hmax[e] = h_max[so_indices[e]]: the greedy reads it like so_data
     DevBuf<GreedyHdr> ghdr;
     DevBuf<double> gX, randv, P, gain, nrm;
-    DevBuf<int> pref, slot, order, rem, glag, rank_part;
+    DevBuf<int> pref, slot, order, rem, glag, rank_part, gsched, gnsteps;
+    DevBuf<unsigned> gmask;
+    DevBuf<GreedyHdr> ghdr_s;  // [steps][GB_WAVES]: the users' headers in schedule order
     Factorizer<T> fac;
     // gap work
     DevBuf<T> g_x, g_l, g_y, g_e1, g_e2, g_r, g_vec, g_tm;
@@ -226,7 +228,41 @@ template <typename T> struct Extras {
                 return fail(MMW_ERR_ARG, "mmw_round: more than 1024 neighbours / slots per user is not supported by the sequential greedy kernel");
             hipLaunchKernelGGL(k_greedy_headers, dim3(grid_elems((size_t)K)), dim3(BLOCK), 0, st, K, order.p, so_indptr.p, q_indptr.p, h_max.p, ghdr.p);
             static const bool sequential = getenv("MMW_GREEDY_SEQ") != nullptr;  // the one-user-per-step kernel, kept for comparison
-            if (!sequential) {
+            static const bool runs_only = getenv("MMW_GREEDY_RUNS") != nullptr;   // contiguous runs instead of the out-of-order schedule
+            if (!sequential && !runs_only) {
+                // steps scheduled out of order (kernels_round.h, k_greedy_schedule): interaction masks of the visiting order, the schedule,
+                // the headers step by step; then one workgroup per attempt follows it
+                MMW_TRY(ensure(gmask, (size_t)K));
+                MMW_TRY(ensure(gsched, (size_t)K * GB_WAVES));
+                MMW_TRY(ensure(gnsteps, 1));
+                MMW_TRY(ensure(ghdr_s, (size_t)K * GB_WAVES));  // (at most K steps)
+                MMW_HIP(hipMemsetAsync(gmask.p, 0, (size_t)K * sizeof(unsigned), st));
+                const size_t pairs = (size_t)K * GS_W;
+                hipLaunchKernelGGL(k_greedy_cmask, dim3((unsigned)((pairs + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, K, (const GreedyHdr*)ghdr.p,
+                                   so_indices.p, q_indices.p, gmask.p);
+                hipLaunchKernelGGL(k_greedy_schedule, dim3(1), dim3(WAVE), 0, st, K, (const unsigned*)gmask.p, gsched.p, gnsteps.p);
+                hipLaunchKernelGGL(k_greedy_sched_headers, dim3(grid_elems((size_t)K * 2)), dim3(BLOCK), 0, st, K, (const int*)gnsteps.p, (const int*)gsched.p,
+                                   (const GreedyHdr*)ghdr.p, ghdr_s.p);
+                if (getenv("MMW_VERBOSE")) {
+                    int ns = 0;
+                    MMW_HIP(hipMemcpyAsync(&ns, gnsteps.p, sizeof(int), hipMemcpyDeviceToHost, st));
+                    MMW_HIP(hipStreamSynchronize(st));
+                    fprintf(stderr, "[round] %d users in %d steps (%.1f per step)\n", K, ns, (double)K / std::max(ns, 1));
+                }
+                const size_t baseb = (size_t)GB_WAVES * Z * 4;
+                if (baseb > 150 * 1024) return fail(MMW_ERR_ARG, "mmw_round: 64 Z bytes exceed the greedy kernel's LDS");
+                const bool slot_lds = baseb + (size_t)K * 4 <= 150 * 1024;
+                const size_t sh = baseb + (slot_lds ? (size_t)K * 4 : 0);
+                if (slot_lds) {
+                    MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_greedy_b<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+                    hipLaunchKernelGGL((k_greedy_b<true, true>), dim3(nb), dim3(GB_WAVES * 64), sh, st, K, Z, (const GreedyHdr*)ghdr_s.p, (const int*)nullptr, pref.p,
+                                       so_indices.p, so_data.p, so_hmax.p, q_indices.p, gain.p, slot.p, rem.p, (const int*)gnsteps.p);
+                } else {
+                    MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_greedy_b<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+                    hipLaunchKernelGGL((k_greedy_b<false, true>), dim3(nb), dim3(GB_WAVES * 64), sh, st, K, Z, (const GreedyHdr*)ghdr_s.p, (const int*)nullptr, pref.p,
+                                       so_indices.p, so_data.p, so_hmax.p, q_indices.p, gain.p, slot.p, rem.p, (const int*)gnsteps.p);
+                }
+            } else if (!sequential) {
                 // several mutually non-interacting users per step (k_greedy_b): interaction lags of the visiting order first
                 MMW_TRY(ensure(glag, (size_t)K));
                 MMW_HIP(hipMemsetAsync(glag.p, 0x7F, (size_t)K * sizeof(int), st));
