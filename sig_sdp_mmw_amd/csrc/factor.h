@@ -75,6 +75,7 @@ template <typename T> struct DenseWork {
     DevBuf<double> G, Q, Q2, G2, Q3, Gpart, cs, diag, dscale, off, scale;
     DevBuf<int> perm, flag;
     DevBuf<double> dfac;  // the current panel's factored diagonal block (k_chol_panel -> k_chol_update)
+    const bool chol_lds = getenv("MMW_CHOL_LDS") != nullptr;  // the panel's diagonal block factored through LDS (for comparison)
     int bcap = 0;
     int sweeps_total = 0, calls_total = 0;
     int ensure(int b, int nslice) {
@@ -216,7 +217,7 @@ template <typename T> struct DenseWork {
         MMW_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), st));
         for (int j0 = 0; j0 < b; j0 += CH_NB) {
             const int below = b - std::min(b, j0 + CH_NB);
-            hipLaunchKernelGGL(k_chol_panel, dim3(std::max(1, (below + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, b, j0, G.p, flag.p, dfac.p);
+            hipLaunchKernelGGL(k_chol_panel, dim3(std::max(1, (below + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, b, j0, G.p, flag.p, dfac.p, chol_lds ? 1 : 0);
             if (below > 0) {
                 const int mt = (below + CH_NB - 1) / CH_NB;
                 hipLaunchKernelGGL(k_chol_update, dim3(mt, mt), dim3(BLOCK), 0, st, b, j0, G.p, (const int*)flag.p, (const double*)dfac.p);

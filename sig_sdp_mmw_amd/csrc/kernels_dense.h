@@ -513,8 +513,14 @@ constexpr int BJ_APPLY_LDS = 3 * BJ_N2 * (BJ_N2 + 1) * (int)sizeof(double);
 // panel's outer product from the trailing lower triangle in 32 x 32 tiles.  (The unblocked one-workgroup version took
 // 5 ms at b = 444; this takes 0.3 ms.)
 constexpr int CH_NB = 32;
+__device__ __forceinline__ double readlane_f64(double v, int l) {  // l: wave-uniform (a constant after unrolling)
+    const long long bits = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(bits & 0xFFFFFFFFll), l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(bits >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 __global__ __launch_bounds__(BLOCK) void k_chol_panel(int b, int j0, double* __restrict__ G, int* __restrict__ flag,
-                                                      double* __restrict__ Dfac /* [32*32] scratch */) {
+                                                      double* __restrict__ Dfac /* [32*32] scratch */, int lds_form = 0) {
     __shared__ double D[CH_NB][CH_NB + 1];
     __shared__ int bad;
     const int nb = min(CH_NB, b - j0);
@@ -526,8 +532,33 @@ __global__ __launch_bounds__(BLOCK) void k_chol_panel(int b, int j0, double* __r
     if (threadIdx.x == 0) bad = *flag;  // an earlier panel already failed: do nothing
     __syncthreads();
     if (bad) return;
-    // The 32 x 32 block is factored by the first wave alone: 32 dependent column steps cost a workgroup barrier each otherwise
-    // (three of them, ~1.5 us per step); inside one wave the LDS is in order and a compiler fence is all a step needs.
+    // The 32 x 32 block is factored by the first wave alone, in registers: lane i owns row i, a column step broadcasts what it needs with
+    // v_readlane (the lane is a constant of the unrolled step) -- 496 broadcast + multiply-add pairs, no LDS round trip, no fence.  The
+    // same operations in the same order as the LDS form below (kept for MMW_CHOL_LDS=1: three fenced LDS phases per column step, ~1 us
+    // each, were 30 of the launch's 59 us).
+    if (!lds_form && threadIdx.x < WAVE) {
+        const int lane = threadIdx.x, row = lane & 31;
+        double a[CH_NB];
+#pragma unroll
+        for (int k = 0; k < CH_NB; ++k) a[k] = D[row][k];
+        bool fail_here = false;
+#pragma unroll
+        for (int j = 0; j < CH_NB; ++j) {
+            const double g = readlane_f64(a[j], j);
+            if (!(g > 0.0)) { fail_here = true; break; }  // (padding rows are the identity's: never here)
+            const double dj = sqrt(g), inv = 1.0 / dj;
+            if (lane == 0) rdiag[j] = inv;
+            a[j] = row == j ? dj : a[j] * inv;
+#pragma unroll
+            for (int k = j + 1; k < CH_NB; ++k) a[k] -= a[j] * readlane_f64(a[j], k);  // (rows above k compute entries nobody reads)
+        }
+        if (fail_here) { if (lane == 0) bad = 1; }
+        else if (lane < CH_NB) {
+#pragma unroll
+            for (int k = 0; k < CH_NB; ++k)
+                if (k <= row) D[row][k] = a[k];
+        }
+    } else
     if (threadIdx.x < WAVE) {
         const int lane = threadIdx.x;
         for (int j = 0; j < nb; ++j) {
