@@ -27,7 +27,9 @@ certified against the tolerance); `value_fp32_operands` is the same loop on stri
 The JSON line also carries
   roofline     : the CSR SpMM inside exp(L/2)R -- algorithmic bytes per launch
                  divided by its mean launch duration, measured with HIP events on the solver's stream
-                 in a second pass over the same steps;
+                 in a second pass over the same steps (matrix-core product: the start / stop events its launch
+                 carries itself, hipExtLaunchKernelGGL -- the dispatch's own begin and end, what a kernel trace
+                 reports; two marker packets around the launch add 1-3 us of marker and dispatch latency);
   coloring     : wall-clock of the binary search on the slot count down to a feasible colouring of the same instance
                  (rank 0, N = 1, one instance per GPU), with the per-probe phase times -- the REFERENCE's search: every probe
                  restarts from Y = 1/C, X = I and runs nit iterations (mmw.py:62-68), state through the host CSR;
@@ -457,6 +459,8 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_source": traffic_src if traffic is not None else None,
                 "bytes_per_launch": int(b_spmm), "avg_launch_us": round(spmm_avg_us, 2),
+                "timing": ("HIP start/stop events carried by each launch (hipExtLaunchKernelGGL)" if kinfo["name"].startswith("k_spmm_mfma") and not os.environ.get("MMW_KT_MARKERS")
+                           else "HIP event markers around each launch"),
                 "avg_launch_us_back_to_back": None if b2b_us is None else round(b2b_us, 2),  # the Lanczos-epilogue launch (two bf16 planes)
                 "avg_launch_us_back_to_back_first_order": None if b2b_first_us is None else round(b2b_first_us, 2),
                 "frac_back_to_back": None if not (b2b_first_us or b2b_us) else round(b_spmm / ((b2b_first_us or b2b_us) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),

@@ -158,7 +158,8 @@ inline unsigned long long* g_mf_stamps = nullptr;  // diagnostic runs only: per-
 template <int MODE>
 inline int spmm_mfma_launch(hipStream_t st, const MfmaDev& M, int mt, int Dpad, size_t plane_bytes, const char* planes, const float* in,
                             float* out, double ascale, double shift, double* partial, double* partial_o2, const ExpmPlan* plan, int step, int* viol,
-                            MfEpi epi = MfEpi{}, int* grid_out = nullptr /* workgroups launched (the first-order epilogue's trace slab) */) {
+                            MfEpi epi = MfEpi{}, int* grid_out = nullptr /* workgroups launched (the first-order epilogue's trace slab) */,
+                            hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr /* recorded by the launch itself (KernelTimers::begin_attached) */) {
     const int ntiles = Dpad / 32;
     const int grid_x = (M.nb + 7) / 8 * 8;
     const int cus = device_cus();
@@ -167,6 +168,11 @@ inline int spmm_mfma_launch(hipStream_t st, const MfmaDev& M, int mt, int Dpad, 
         constexpr int gtw = (NW / MS) * NT;                                                                                            \
         constexpr int lds_bytes = mf_lds_bytes<MT, gtw, KC, NB, mf_planes(MODE), mf_apieces(MODE)>();                                  \
         MMW_TRY(set_max_lds(reinterpret_cast<const void*>(&k_spmm_mfma<MODE, MT, NT, NW, MS, KC, NB>), lds_bytes));                    \
+        if (ev_a)                                                                                                                      \
+            hipExtLaunchKernelGGL((k_spmm_mfma<MODE, MT, NT, NW, MS, KC, NB>), dim3(grid_x, (ntiles + gtw - 1) / gtw), dim3(NW * 64),  \
+                                  lds_bytes, st, ev_a, ev_b, 0, M, Dpad, plane_bytes, planes, in, out, ascale, shift, partial,         \
+                                  partial_o2, plan, step, viol, g_mf_stamps, epi);                                                     \
+        else                                                                                                                           \
         hipLaunchKernelGGL((k_spmm_mfma<MODE, MT, NT, NW, MS, KC, NB>), dim3(grid_x, (ntiles + gtw - 1) / gtw), dim3(NW * 64),         \
                            lds_bytes, st, M, Dpad, plane_bytes, planes, in, out, ascale, shift, partial, partial_o2,                   \
                            plan, step, viol, g_mf_stamps, epi);                                                                        \
@@ -383,9 +389,10 @@ template <typename T> struct ExpmEngine {
         if constexpr (std::is_same<T, float>::value && (MODE == SPMM_PLAIN || MODE == SPMM_LANCZOS)) {
             if (planes_in && mfma_now()) {
                 MMW_TRY(check_slabs(mf.nb));
-                MMW_TRY(kbegin(KT_SPMM));
+                hipEvent_t ea = nullptr, eb = nullptr;
+                if (kt) MMW_TRY(kt->begin_attached(KT_SPMM, &ea, &eb));
                 MMW_TRY((spmm_mfma_launch<MODE>(st, mf, mf_mt, lay.Dpad, bs * sizeof(unsigned short), reinterpret_cast<const char*>(planes_in), in, out, ascale,
-                                                shift, partial.p, apost() ? partial_o2.p : nullptr, plan, step, viol_d.p)));
+                                                shift, partial.p, apost() ? partial_o2.p : nullptr, plan, step, viol_d.p, MfEpi{}, nullptr, ea, eb)));
                 return kend();
             }
         }
@@ -486,15 +493,16 @@ template <typename T> struct ExpmEngine {
             MfEpi E;
             E.y_planes = y_planes; E.dfx = dfx; E.tr_part = tr_part;
             MMW_TRY(check_slabs(mf.nb));
-            MMW_TRY(kbegin(KT_SPMM));
+            hipEvent_t ea = nullptr, eb = nullptr;
+            if (kt) MMW_TRY(kt->begin_attached(KT_SPMM, &ea, &eb));
             if (afrag16) {
                 MfmaDev m16 = mf;
                 m16.afrag = reinterpret_cast<const unsigned*>(afrag16);
                 MMW_TRY((spmm_mfma_launch<SPMM_FIRST16>(st, m16, mf_mt, lay.Dpad, bs * sizeof(unsigned short), reinterpret_cast<const char*>(planes_of(0)), U.p, out,
-                                                        ascale / (double)MF_F16_SCALE, 0.0, partial.p, partial_o2.p, plan_d.p, 1, viol_d.p, E, ntr)));
+                                                        ascale / (double)MF_F16_SCALE, 0.0, partial.p, partial_o2.p, plan_d.p, 1, viol_d.p, E, ntr, ea, eb)));
             } else
                 MMW_TRY((spmm_mfma_launch<SPMM_FIRST>(st, mf, mf_mt, lay.Dpad, bs * sizeof(unsigned short), reinterpret_cast<const char*>(planes_of(0)), U.p, out,
-                                                      ascale / (double)MF_F16_SCALE, 0.0, partial.p, partial_o2.p, plan_d.p, 1, viol_d.p, E, ntr)));
+                                                      ascale / (double)MF_F16_SCALE, 0.0, partial.p, partial_o2.p, plan_d.p, 1, viol_d.p, E, ntr, ea, eb)));
             MMW_TRY(kend());
             planes_ready[0] = false;
             planes0_f16 = false;

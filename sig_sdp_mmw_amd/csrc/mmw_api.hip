@@ -862,6 +862,7 @@ template <typename T> struct Solver final : mmw_solver {
         MMW_TRY(sync());
         kt.on = enabled != 0;
         kt_shipped = enabled == 2;  // 2: time the launches of the shipped path (chunks without readback, riding workgroups) as they are
+        kt.attach = kt_shipped && !getenv("MMW_KT_MARKERS");  // ... the matrix-core product by the events its launch carries itself
         eng.kt_exact = kt.on && !kt_shipped;
         kt.clear();
         return MMW_OK;
