@@ -529,6 +529,8 @@ __global__ __launch_bounds__(BLOCK) void k_chol_panel(int b, int j0, double* __r
         D[i][k] = (i < nb && k <= i) ? G[(size_t)(j0 + i) * b + j0 + k] : (i == k ? 1.0 : 0.0);
     }
     __shared__ double rdiag[CH_NB];  // 1 / D[k][k]
+    __shared__ double Di[CH_NB][CH_NB + 1];  // D^-1, zero above the diagonal (padded: the matrix-core operand read walks a column)
+    double* const Di_l = &Di[0][0];
     if (threadIdx.x == 0) bad = *flag;  // an earlier panel already failed: do nothing
     __syncthreads();
     if (bad) return;
@@ -542,21 +544,38 @@ __global__ __launch_bounds__(BLOCK) void k_chol_panel(int b, int j0, double* __r
 #pragma unroll
         for (int k = 0; k < CH_NB; ++k) a[k] = D[row][k];
         bool fail_here = false;
+        double rinv[CH_NB];  // 1 / D[j][j] (the same value in every lane)
 #pragma unroll
         for (int j = 0; j < CH_NB; ++j) {
             const double g = readlane_f64(a[j], j);
             if (!(g > 0.0)) { fail_here = true; break; }  // (padding rows are the identity's: never here)
             const double dj = sqrt(g), inv = 1.0 / dj;
+            rinv[j] = inv;
             if (lane == 0) rdiag[j] = inv;
             a[j] = row == j ? dj : a[j] * inv;
 #pragma unroll
             for (int k = j + 1; k < CH_NB; ++k) a[k] -= a[j] * readlane_f64(a[j], k);  // (rows above k compute entries nobody reads)
         }
         if (fail_here) { if (lane == 0) bad = 1; }
-        else if (lane < CH_NB) {
+        else {
+            if (lane < CH_NB) {
 #pragma unroll
-            for (int k = 0; k < CH_NB; ++k)
-                if (k <= row) D[row][k] = a[k];
+                for (int k = 0; k < CH_NB; ++k)
+                    if (k <= row) D[row][k] = a[k];
+            }
+            // the inverse of the factor the same way: lane c solves column c, row k of the factor comes by broadcast
+            double di[CH_NB];
+#pragma unroll
+            for (int k = 0; k < CH_NB; ++k) {
+                double sdi = 0.0;
+#pragma unroll
+                for (int m = 0; m < k; ++m) sdi += readlane_f64(a[m], k) * di[m];  // (di[m] = 0 above the column's diagonal)
+                di[k] = k < row ? 0.0 : (k == row ? rinv[k] : -sdi * rinv[k]);
+            }
+            if (lane < CH_NB) {
+#pragma unroll
+                for (int k = 0; k < CH_NB; ++k) Di_l[k * (CH_NB + 1) + row] = di[k];
+            }
         }
     } else
     if (threadIdx.x < WAVE) {
@@ -602,8 +621,7 @@ __global__ __launch_bounds__(BLOCK) void k_chol_panel(int b, int j0, double* __r
     // rows below the diagonal block: x = g D^-T, one thread per row, as a product with the explicit inverse of the 32 x 32 factor
     // (its rows read as LDS broadcasts, the row of g in registers, the output column in a rolled loop).  The substitution
     // form of the same triangle, fully unrolled, makes the compiler hoist 496 LDS reads: 512 VGPRs, 2.4 KB of scratch, 54 us.
-    __shared__ double Di[CH_NB][CH_NB];  // D^-1, zero above the diagonal
-    if (threadIdx.x < CH_NB) {  // lane c solves column c of the inverse
+    if (lds_form && threadIdx.x < CH_NB) {  // lane c solves column c of the inverse
         const int c = threadIdx.x;
         for (int k = 0; k < CH_NB; ++k) {
             double v = 0.0;
@@ -617,19 +635,50 @@ __global__ __launch_bounds__(BLOCK) void k_chol_panel(int b, int j0, double* __r
         }
     }
     __syncthreads();
-    const int r = j0 + nb + blockIdx.x * BLOCK + threadIdx.x;
-    if (r < b) {
-        double gr[CH_NB];
-        double* g = G + (size_t)r * b + j0;
+    if (lds_form) {  // one thread per row: 32 loads and 32 stores of 8 bytes, each thread on a row of its own
+        const int r = j0 + nb + blockIdx.x * BLOCK + threadIdx.x;
+        if (r < b) {
+            double gr[CH_NB];
+            double* g = G + (size_t)r * b + j0;
 #pragma unroll
-        for (int c = 0; c < CH_NB; ++c) gr[c] = g[c < nb ? c : nb - 1];  // the padding columns of D^-1 are the identity's: unused
+            for (int c = 0; c < CH_NB; ++c) gr[c] = g[c < nb ? c : nb - 1];  // the padding columns of D^-1 are the identity's: unused
 #pragma unroll 1
-        for (int k = 0; k < nb; ++k) {
-            double s = 0.0;
+            for (int k = 0; k < nb; ++k) {
+                double s = 0.0;
 #pragma unroll
-            for (int c = 0; c < CH_NB; ++c) s += gr[c] * Di[k][c];
-            g[k] = s;
+                for (int c = 0; c < CH_NB; ++c) s += gr[c] * Di[k][c];
+                g[k] = s;
+            }
         }
+        return;
+    }
+    // (rows exist below the block only when the block is a full one: nb == CH_NB here.)  64 rows at a time through LDS -- a row's 32
+    // values are one 256-byte run -- and X = G_rows D^-T on the fp64 matrix cores, wave w its 16 rows x 32 columns.
+    __shared__ double Gt[64][CH_NB + 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
+    for (int sub = 0; sub < BLOCK / 64; ++sub) {
+        const int r0 = j0 + nb + blockIdx.x * BLOCK + sub * 64;
+        if (r0 >= b) break;  // (uniform)
+        for (int o = threadIdx.x; o < 64 * CH_NB; o += BLOCK) {
+            const int rr = o / CH_NB, c = o % CH_NB;
+            Gt[rr][c] = r0 + rr < b ? G[(size_t)(r0 + rr) * b + j0 + c] : 0.0;
+        }
+        __syncthreads();
+        d4 acc[2] = {(d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+        for (int kk = 0; kk < CH_NB; kk += 4) {
+            const double a = Gt[16 * wv + li][kk + lk];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Di[16 * t + li][kk + lk], acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = r0 + 16 * wv + lk + 4 * q;
+                if (r < b) G[(size_t)r * b + j0 + 16 * t + li] = acc[t][q];
+            }
+        __syncthreads();
     }
 }
 // trailing update after panel [j0, j0+nb): G[i][k] -= sum_c L[i][j0+c] L[k][j0+c] for j0+nb <= k <= i < b, 32 x 32 tiles
