@@ -75,6 +75,7 @@ template <typename T> struct DenseWork {
     DevBuf<double> G, Q, Q2, G2, Q3, Gpart, cs, diag, dscale, off, scale;
     DevBuf<int> perm, flag;
     DevBuf<double> dfac;  // the current panel's factored diagonal block (k_chol_panel -> k_chol_update)
+    DevBuf<double> dinv;  // the inverses of all diagonal blocks of the last factor (k_chol_panel -> k_trsm_blocked)
     const bool chol_lds = getenv("MMW_CHOL_LDS") != nullptr;  // the panel's diagonal block factored through LDS (for comparison)
     int bcap = 0;
     int sweeps_total = 0, calls_total = 0;
@@ -212,12 +213,14 @@ template <typename T> struct DenseWork {
     int chol_factor(int b, bool* ok) {
         if (flag.n < 1) MMW_TRY(flag.alloc(1));
         if (dfac.n < (size_t)CH_NB * CH_NB) MMW_TRY(dfac.alloc((size_t)CH_NB * CH_NB));
+        const size_t n_inv = (size_t)((b + CH_NB - 1) / CH_NB) * CH_NB * CH_NB;
+        if (dinv.n < n_inv) MMW_TRY(dinv.alloc(n_inv));
         hipLaunchKernelGGL(k_scale_sym, dim3(grid_elems(b)), dim3(BLOCK), 0, st, b, G.p, dscale.p);
         hipLaunchKernelGGL(k_apply_scale_sym, dim3(grid_elems((size_t)b * b)), dim3(BLOCK), 0, st, b, G.p, dscale.p);
         MMW_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), st));
         for (int j0 = 0; j0 < b; j0 += CH_NB) {
             const int below = b - std::min(b, j0 + CH_NB);
-            hipLaunchKernelGGL(k_chol_panel, dim3(std::max(1, (below + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, b, j0, G.p, flag.p, dfac.p, chol_lds ? 1 : 0);
+            hipLaunchKernelGGL(k_chol_panel, dim3(std::max(1, (below + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, b, j0, G.p, flag.p, dfac.p, chol_lds ? 1 : 0, dinv.p);
             if (below > 0) {
                 const int mt = (below + CH_NB - 1) / CH_NB;
                 hipLaunchKernelGGL(k_chol_update, dim3(mt, mt), dim3(BLOCK), 0, st, b, j0, G.p, (const int*)flag.p, (const double*)dfac.p);
@@ -343,8 +346,13 @@ template <typename T> struct Factorizer {
                 MMW_HIP(hipMemsetAsync(B.p, 0, (size_t)K * ld * sizeof(T), st));
                 MMW_TRY(dw.gemm(K, b, b, ld, A.p, dw.Q2.p, b, B.p));
             } else {  // V <- (V D) L^{-T} by forward substitution on the rows
-                hipLaunchKernelGGL((k_trsm_rows<T>), dim3(grid_rows(K)), dim3(BLOCK), (size_t)WAVES_PER_BLOCK * b * sizeof(double), st, K, b, ld,
-                                   A.p, dw.G.p, dw.dscale.p, B.p);
+                static const bool trsm_rows = getenv("MMW_TRSM_ROWS") != nullptr;  // one wavefront per row (for comparison)
+                if (trsm_rows)
+                    hipLaunchKernelGGL((k_trsm_rows<T>), dim3(grid_rows(K)), dim3(BLOCK), (size_t)WAVES_PER_BLOCK * b * sizeof(double), st, K, b, ld,
+                                       A.p, dw.G.p, dw.dscale.p, B.p);
+                else
+                    hipLaunchKernelGGL((k_trsm_blocked<T>), dim3((K + 63) / 64), dim3(BLOCK), 0, st, K, b, ld, (const T*)A.p, (const double*)dw.G.p,
+                                       (const double*)dw.dscale.p, (const double*)dw.dinv.p, B.p);
                 MMW_HIP(hipGetLastError());
             }
             std::swap(A.p, B.p);
